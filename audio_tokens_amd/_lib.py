@@ -1,0 +1,116 @@
+"""ctypes binding of libaudio_tokens_amd.so (the C ABI declared in include/audio_tokens_amd.h).
+
+There is no fallback of any kind: if the shared library is missing, or the device is not a
+gfx950, every operator raises.  Tensors are PyTorch-ROCm tensors used as storage only -- the
+library receives `data_ptr()` and the current HIP stream handle.
+"""
+from __future__ import annotations
+
+import ctypes
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libaudio_tokens_amd.so"
+
+AT_LAYOUT_MEL_MAJOR = 0
+AT_LAYOUT_FRAME_MAJOR = 1
+
+_c = ctypes
+_vp, _i32, _i64 = _c.c_void_p, _c.c_int, _c.c_int64
+
+# name -> (restype, argtypes); kept in one table so tests can check every declared symbol exports
+SIGNATURES = {
+    "at_version": (_i32, []),
+    "at_last_error": (_c.c_char_p, []),
+    "at_create": (_i32, [_i32, _c.POINTER(_vp)]),
+    "at_destroy": (None, [_vp]),
+    "at_workspace_bytes": (_i64, [_vp]),
+    "at_rand_perm_mt19937": (_i32, [_i64, _i64, _vp]),
+    "at_rand_perm_prefix_mt19937": (_i32, [_i64, _i64, _i64, _vp]),
+    "at_mel_filterbank_host": (_i32, [_i32, _i32, _i32, _vp]),
+    "at_num_frames": (_i64, [_i64, _i32]),
+    "at_split_clusters_host": (_i32, [_i32, _i32, _i64, _vp, _vp, _c.POINTER(_i32)]),
+    "at_logmel_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),
+    "at_l2norm_rows_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "at_assign_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp]),
+    "at_gather_rows_f32": (_i32, [_vp, _vp, _i32, _vp, _i64, _vp, _vp]),
+    "at_centroid_accum_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp]),
+    "at_centroid_finalize_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "at_sum_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "at_any_nonfinite_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+}
+
+_lib = None
+
+
+class NativeLibraryError(ImportError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load (once) and type the shared library.  Raises NativeLibraryError if it is not built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise NativeLibraryError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run "
+                f"`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C {_PKG / 'csrc'}`). "
+                "audio_tokens_amd has no CPU fallback."
+            )
+        lib = ctypes.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError here = header / library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    return load().at_last_error().decode("utf-8", "replace")
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"audio_tokens_amd native error {code}: {msg}")
+        self.code = code
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise NativeError(rc, last_error())
+
+
+class Context:
+    """One at_ctx (per-device workspace).  Not re-entrant: one per host thread."""
+
+    def __init__(self, device_index: int):
+        self.lib = load()
+        self.device_index = int(device_index)
+        h = _vp()
+        check(self.lib.at_create(self.device_index, ctypes.byref(h)))
+        self.handle = h
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.at_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover - interpreter shutdown order
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def workspace_bytes(self) -> int:
+        return int(self.lib.at_workspace_bytes(self.handle))
+
+
+_contexts: dict[int, Context] = {}
+
+
+def context(device_index: int) -> Context:
+    ctx = _contexts.get(device_index)
+    if ctx is None:
+        ctx = _contexts[device_index] = Context(device_index)
+    return ctx

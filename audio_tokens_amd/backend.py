@@ -1,0 +1,236 @@
+"""Tensor-level front end of the C ABI: PyTorch-ROCm tensors in, PyTorch-ROCm tensors out.
+
+`HipBackend` is the only compute backend the package ships.  It hands `data_ptr()`s and the
+current HIP stream to libaudio_tokens_amd.so and never computes anything itself; if the library
+or a gfx950 device is missing it raises.  (tests/ drive the same host logic with a CPU stand-in
+built on the oracle, to cover the multi-rank code path under gloo; that stand-in lives in tests/,
+not here.)
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_vp = ctypes.c_void_p
+
+
+def _ptr(t) -> _vp:
+    return _vp(t.data_ptr()) if t is not None else _vp(None)
+
+
+def _np_ptr(a: np.ndarray) -> _vp:
+    return _vp(a.ctypes.data)
+
+
+class HostHelpers:
+    """The sequential, RNG-driven host pieces of the FAISS recipe (native C++, no GPU needed)."""
+
+    def __init__(self):
+        self.lib = _lib.load()
+
+    def rand_perm(self, n: int, seed: int) -> np.ndarray:
+        out = np.empty(n, np.int32)
+        _lib.check(self.lib.at_rand_perm_mt19937(n, seed, _np_ptr(out)))
+        return out
+
+    def rand_perm_prefix(self, n: int, seed: int, m: int) -> np.ndarray:
+        out = np.empty(m, np.int32)
+        _lib.check(self.lib.at_rand_perm_prefix_mt19937(n, seed, m, _np_ptr(out)))
+        return out
+
+    def mel_filterbank(self, sample_rate: int, n_fft: int, n_mels: int) -> np.ndarray:
+        fb = np.empty((n_fft // 2 + 1, n_mels), np.float32)
+        _lib.check(self.lib.at_mel_filterbank_host(sample_rate, n_fft, n_mels, _np_ptr(fb)))
+        return fb
+
+    def num_frames(self, L: int, hop: int) -> int:
+        return int(self.lib.at_num_frames(L, hop))
+
+    def split_clusters(self, hassign: np.ndarray, centroids: np.ndarray, n: int) -> int:
+        """In place on two C-contiguous float32 host arrays; returns nsplit."""
+        assert hassign.dtype == np.float32 and centroids.dtype == np.float32
+        assert hassign.flags.c_contiguous and centroids.flags.c_contiguous
+        k, d = centroids.shape
+        ns = ctypes.c_int(0)
+        _lib.check(self.lib.at_split_clusters_host(d, k, n, _np_ptr(hassign), _np_ptr(centroids),
+                                                   ctypes.byref(ns)))
+        return int(ns.value)
+
+
+class HipBackend(HostHelpers):
+    def __init__(self, device=None):
+        super().__init__()
+        if not torch.cuda.is_available():
+            raise RuntimeError("audio_tokens_amd: no ROCm device visible (torch.cuda.is_available() "
+                               "is False) and there is no CPU fallback")
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError(f"audio_tokens_amd: device must be a ROCm GPU, got {device}")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = device
+        self.ctx = _lib.context(device.index)
+
+    # -- plumbing --------------------------------------------------------------------------
+    def _stream(self) -> _vp:
+        return _vp(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _f32(self, t, name="tensor") -> torch.Tensor:
+        if isinstance(t, np.ndarray):
+            t = torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32))
+        if t.dtype != torch.float32:
+            t = t.float()
+        if t.device != self.device:
+            t = t.to(self.device, non_blocking=True)
+        if not t.is_contiguous():
+            t = t.contiguous()
+        return t
+
+    def empty(self, shape, dtype=torch.float32) -> torch.Tensor:
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def zeros(self, shape, dtype=torch.float32) -> torch.Tensor:
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    def from_host(self, a, dtype=None) -> torch.Tensor:
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.to(self.device, non_blocking=False)
+
+    def to_host(self, t: torch.Tensor) -> np.ndarray:
+        return t.detach().cpu().numpy()
+
+    def host_staging(self, shape, dtype) -> torch.Tensor:
+        """Pinned host buffer for small asynchronous read-backs."""
+        return torch.empty(shape, dtype=dtype).pin_memory()
+
+    def synchronize(self) -> None:
+        torch.cuda.current_stream(self.device).synchronize()
+
+    # -- operators ---------------------------------------------------------------------------
+    def logmel(self, wave, sample_rate=22050, n_fft=512, hop=128, n_mels=64, fb=None,
+               frame_major=False, l2norm=False, out=None) -> torch.Tensor:
+        """wave [n_clips, L] (or [L]) -> [n_clips, n_mels, T], or [n_clips*T, n_mels] if frame_major."""
+        wave = self._f32(wave)
+        if wave.dim() == 1:
+            wave = wave.unsqueeze(0)
+        assert wave.dim() == 2
+        n_clips, L = wave.shape
+        T = self.num_frames(L, hop)
+        fbt = self._f32(fb) if fb is not None else None
+        if fbt is not None:
+            assert tuple(fbt.shape) == (n_fft // 2 + 1, n_mels), "fb must be [n_fft/2+1, n_mels]"
+        shape = (n_clips * T, n_mels) if frame_major else (n_clips, n_mels, T)
+        if out is None:
+            out = self.empty(shape)
+        else:
+            assert out.is_contiguous() and out.dtype == torch.float32 and out.numel() == n_clips * T * n_mels
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_logmel_f32(
+                self.ctx.handle, _ptr(wave), n_clips, L, wave.stride(0), sample_rate, n_fft, hop, n_mels,
+                _ptr(fbt), _ptr(out), _lib.AT_LAYOUT_FRAME_MAJOR if frame_major else _lib.AT_LAYOUT_MEL_MAJOR,
+                1 if l2norm else 0, self._stream()))
+        return out
+
+    def l2norm_rows(self, x, out=None) -> torch.Tensor:
+        x = self._f32(x)
+        assert x.dim() == 2
+        n, d = x.shape
+        if out is None:
+            out = torch.empty_like(x)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_l2norm_rows_f32(self.ctx.handle, _ptr(x), n, d, _ptr(out), self._stream()))
+        return out
+
+    def assign(self, x, c, want_dist=True):
+        x, c = self._f32(x), self._f32(c)
+        assert x.dim() == 2 and c.dim() == 2 and x.shape[1] == c.shape[1]
+        n, d = x.shape
+        k = c.shape[0]
+        ids = self.empty((n,), torch.int64)
+        dist = self.empty((n,), torch.float32) if want_dist else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_assign_f32(self.ctx.handle, _ptr(x), n, d, _ptr(c), k, _ptr(ids),
+                                              _ptr(dist), self._stream()))
+        return ids, dist
+
+    def gather_rows(self, x, idx) -> torch.Tensor:
+        x = self._f32(x)
+        if isinstance(idx, np.ndarray):
+            idx = self.from_host(idx.astype(np.int32, copy=False))
+        assert idx.dtype == torch.int32 and idx.is_contiguous() and idx.device == self.device
+        m, d = idx.numel(), x.shape[1]
+        out = self.empty((m, d))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_gather_rows_f32(self.ctx.handle, _ptr(x), d, _ptr(idx), m, _ptr(out),
+                                                   self._stream()))
+        return out
+
+    def centroid_accum(self, x, ids, k, out=None) -> torch.Tensor:
+        """Packed partial result [k*d + k]: sums [k, d] followed by counts [k]."""
+        x = self._f32(x)
+        n, d = x.shape
+        assert ids.dtype == torch.int64 and ids.is_contiguous() and ids.numel() == n
+        if out is None:
+            out = self.empty((k * d + k,))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_centroid_accum_f32(
+                self.ctx.handle, _ptr(x), n, d, _ptr(ids), k, _ptr(out), _vp(out.data_ptr() + 4 * k * d),
+                self._stream()))
+        return out
+
+    def centroid_finalize(self, parts, k, d):
+        """parts [n_parts, k*d + k] packed partials (rank order) -> (centroids [k, d], hassign [k])."""
+        if parts.dim() == 1:
+            parts = parts.unsqueeze(0)
+        assert parts.is_contiguous() and parts.shape[1] == k * d + k
+        n_parts = parts.shape[0]
+        cent = self.empty((k, d))
+        hassign = self.empty((k,))
+        stride = parts.stride(0)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_centroid_finalize_f32(
+                self.ctx.handle, _ptr(parts), stride, _vp(parts.data_ptr() + 4 * k * d), stride, n_parts,
+                k, d, _ptr(cent), _ptr(hassign), self._stream()))
+        return cent, hassign
+
+    def sum_f64(self, v) -> torch.Tensor:
+        """Device double scalar (shape [1]); no synchronisation."""
+        v = self._f32(v)
+        out = self.empty((1,), torch.float64)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_sum_f32(self.ctx.handle, _ptr(v), v.numel(), _ptr(out), self._stream()))
+        return out
+
+    def any_nonfinite(self, v) -> bool:
+        v = self._f32(v)
+        flag = self.empty((1,), torch.int32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_any_nonfinite_f32(self.ctx.handle, _ptr(v), v.numel(), _ptr(flag),
+                                                     self._stream()))
+        return bool(flag.item())
+
+
+_default: dict = {}
+
+
+def default_backend(device=None) -> HipBackend:
+    """Process-wide HipBackend per device (creates the at_ctx on first use)."""
+    if device is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("audio_tokens_amd: no ROCm device visible and there is no CPU fallback")
+        idx = torch.cuda.current_device()
+    else:
+        device = torch.device(device)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+    be = _default.get(idx)
+    if be is None:
+        be = _default[idx] = HipBackend(torch.device("cuda", idx))
+    return be

@@ -1,0 +1,361 @@
+// assign.hip -- nearest centroid under squared L2 on gfx950 (at_assign_f32).
+//
+// Replaces faiss.IndexFlatL2.search(x, 1) at processors/spec_tokenizer.py:77 and inside
+// faiss.Kmeans.train (processors/cluster_creator.py:54-56) of danavery/audio-tokens.
+//
+// Arithmetic contract (identical to oracle/oracle.c orc_assign, bit for bit):
+//   ip(i,j)  = fmaf chain over the feature index, ascending, from +0   (v_mfma_f32_32x32x2_f32)
+//   xn(i), cn(j) likewise with both operands equal
+//   dis(i,j) = max(0, (xn + cn) - 2*ip)            one rounding for the add, one for the fma
+//   ids[i]   = lowest j with minimal dis, dist[i] = that dis
+//
+// Data flow.  The centroid table is re-laid once per call into 64-centroid tiles whose rows are
+// already in LDS order (k split even/odd per 8 features so that one ds_read_b128 feeds four
+// consecutive MFMA k-steps, 16-byte chunks XOR-swizzled by row so the reads are conflict free),
+// each tile followed by its 64 squared norms.  A workgroup of 4 waves streams every tile through a
+// double-buffered LDS copy while each wave keeps its 32*NB rows of x in registers for the whole
+// sweep (B operand: lane l holds x[row l&31][k = 2s + (l>>5)]); the 32x32 accumulator puts the x
+// row on the lane and 16 centroids in the registers, so the running arg-min is lane-local and the
+// two half-waves are merged once at the end.  HBM traffic: x once (4d B/row) + 12 B/row out;
+// the centroid image (k*d*4 B) is L2/Infinity-Cache resident.  Bound: fp32 MFMA (2*d*k flop/row).
+#include "at_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int CT = 64;        // centroid rows per image tile
+constexpr int WG = 256;       // threads per workgroup (4 waves)
+
+__host__ __device__ constexpr int tile_floats(int dp) { return CT * dp + CT; }
+
+// ---------------------------------------------------------------------------------------------
+// Centroid image: tile t holds rows t*64 .. t*64+63.  Row r, 16-byte chunk pc (physical) holds
+// logical chunk lc = pc ^ (r & 15); lc = 2q + h holds features 8q + {0,2,4,6} + h.  Features
+// >= d and rows >= k are zero; |c|^2 of a row >= k is +inf so it can never win.
+__global__ void __launch_bounds__(WG) prep_centroids_kernel(const float* __restrict__ c, int k, int d,
+                                                            int dp, float* __restrict__ img) {
+    const int t = blockIdx.x;
+    float* out = img + (size_t)t * tile_floats(dp);
+    const int chunks_per_row = dp / 4;
+    for (int e = threadIdx.x; e < CT * chunks_per_row; e += WG) {
+        const int r = e / chunks_per_row, pc = e % chunks_per_row;
+        const int lc = pc ^ (r & 15);
+        const int q = lc >> 1, h = lc & 1;
+        const int row = t * CT + r;
+        f32x4 v;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int f = 8 * q + 2 * u + h;
+            v[u] = (row < k && f < d) ? c[(size_t)row * d + f] : 0.0f;
+        }
+        *reinterpret_cast<f32x4*>(out + (size_t)r * dp + pc * 4) = v;
+    }
+    if (threadIdx.x < CT) {
+        const int row = t * CT + threadIdx.x;
+        float nrm = __builtin_inff();
+        if (row < k) {
+            nrm = 0.0f;
+            for (int f = 0; f < d; f++) {
+                const float v = c[(size_t)row * d + f];
+                nrm = __builtin_fmaf(v, v, nrm);
+            }
+        }
+        out[CT * dp + threadIdx.x] = nrm;
+    }
+}
+
+
+// One arg-min step with the compare mask kept in VCC (three VALU ops, no SGPR pair to carry):
+//   keep = !(dis < bd);  bd = keep ? bd : dis;  br = keep ? br : R
+template <int R>
+__device__ __forceinline__ void argmin_step(float& bd, unsigned& br, float dis) {
+    asm("v_cmp_nlt_f32 vcc, %2, %0\n\t"
+        "v_cndmask_b32 %0, %2, %0, vcc\n\t"
+        "v_cndmask_b32 %1, %3, %1, vcc"
+        : "+v"(bd), "+v"(br)
+        : "v"(dis), "n"(R)
+        : "vcc");
+}
+
+// dis = max(0, (xn + cn) - 2*ip) for accumulator register R, then the arg-min step.
+template <int R>
+__device__ __forceinline__ void epilogue_from(float& bd, unsigned& br, const f32x16& acc, float xn,
+                                              const f32x4 (&cnv)[4]) {
+    if constexpr (R < 16) {
+        const float t = xn + cnv[R >> 2][R & 3];
+        float dis = __builtin_fmaf(-2.0f, acc[R], t);
+        dis = __builtin_fmaxf(dis, 0.0f);
+        argmin_step<R>(bd, br, dis);
+        epilogue_from<R + 1>(bd, br, acc, xn, cnv);
+    }
+}
+
+__device__ __forceinline__ void epilogue16(float& bd, unsigned& br, const f32x16& acc, float xn,
+                                           const f32x4 (&cnv)[4]) {
+    epilogue_from<0>(bd, br, acc, xn, cnv);
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int D, int NB>
+__global__ void __launch_bounds__(WG, 2)
+assign_mfma_kernel(const float* __restrict__ X, long n, const float* __restrict__ img, int ntiles,
+                   long* __restrict__ ids, float* __restrict__ dist) {
+    constexpr int TILE_F = tile_floats(D);
+    constexpr int NV = TILE_F / 4;               // float4 per tile image
+    constexpr int VPT = (NV + WG - 1) / WG;      // float4 staged per thread
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 * TILE_F floats
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int j = lane & 31;   // x row within a 32-row tile == accumulator column
+    const int h = lane >> 5;   // which k of each MFMA k-pair this lane feeds
+    const long row0 = ((long)blockIdx.x * 4 + wave) * (32 * NB);
+
+    // ---- x rows -> registers (B operand), |x|^2 as the ascending fmaf chain ----
+    float xr[NB][D / 2];
+    float xn[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        long r = row0 + 32 * b + j;
+        if (r >= n) r = n - 1;
+        const f32x4* p = reinterpret_cast<const f32x4*>(X + r * D);
+        float nrm = 0.0f;
+#pragma unroll
+        for (int q = 0; q < D / 8; q++) {
+            const f32x4 u = p[2 * q], v = p[2 * q + 1];
+            nrm = __builtin_fmaf(u[0], u[0], nrm);
+            nrm = __builtin_fmaf(u[1], u[1], nrm);
+            nrm = __builtin_fmaf(u[2], u[2], nrm);
+            nrm = __builtin_fmaf(u[3], u[3], nrm);
+            nrm = __builtin_fmaf(v[0], v[0], nrm);
+            nrm = __builtin_fmaf(v[1], v[1], nrm);
+            nrm = __builtin_fmaf(v[2], v[2], nrm);
+            nrm = __builtin_fmaf(v[3], v[3], nrm);
+            xr[b][4 * q + 0] = h ? u[1] : u[0];
+            xr[b][4 * q + 1] = h ? u[3] : u[2];
+            xr[b][4 * q + 2] = h ? v[1] : v[0];
+            xr[b][4 * q + 3] = h ? v[3] : v[2];
+        }
+        xn[b] = nrm;
+    }
+
+    float bestd[NB];
+    unsigned bestc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        bestd[b] = __builtin_inff();
+        bestc[b] = 0xffffffffu;
+    }
+
+    // ---- stage tile 0 ----
+    f32x4 pf[VPT];
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(img);
+#pragma unroll
+        for (int v = 0; v < VPT; v++) {
+            const int e = tid + v * WG;
+            if (e < NV) reinterpret_cast<f32x4*>(smem)[e] = src[e];
+        }
+    }
+    __syncthreads();
+
+    const int swz = j & 15;
+    for (int ct = 0; ct < ntiles; ct++) {
+        const float* cur = smem + (ct & 1) * TILE_F;
+        const bool more = ct + 1 < ntiles;
+        if (more) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(img + (size_t)(ct + 1) * TILE_F);
+#pragma unroll
+            for (int v = 0; v < VPT; v++) {
+                const int e = tid + v * WG;
+                if (e < NV) pf[v] = src[e];
+            }
+        }
+
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            // |c|^2 of this lane's 16 accumulator rows: rows a*32 + 8g + 4h + (0..3)
+            f32x4 cnv[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                cnv[g] = *reinterpret_cast<const f32x4*>(cur + CT * D + a * 32 + 8 * g + 4 * h);
+            const float* arow = cur + (a * 32 + j) * D;
+            const unsigned codebase = (unsigned)(ct * 2 + a) * 16u;
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < D / 8; q++) {
+                    const int pc = (2 * q + h) ^ swz;
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(arow + pc * 4);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], xr[b][4 * q + 0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], xr[b][4 * q + 1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], xr[b][4 * q + 2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], xr[b][4 * q + 3], acc, 0, 0, 0);
+                }
+                // running arg-min over this lane's 16 centroids (ascending index == ascending r)
+                float bd = bestd[b];
+                unsigned br = 16u;  // 16 = "no improvement in this job"
+                epilogue16(bd, br, acc, xn[b], cnv);
+                bestd[b] = bd;
+                bestc[b] = br != 16u ? (codebase | br) : bestc[b];
+            }
+        }
+
+        if (more) {
+            f32x4* dst = reinterpret_cast<f32x4*>(smem + ((ct + 1) & 1) * TILE_F);
+#pragma unroll
+            for (int v = 0; v < VPT; v++) {
+                const int e = tid + v * WG;
+                if (e < NV) dst[e] = pf[v];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- merge the two half-waves (rows 4h + ... of every 8-row group) and store ----
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        int idx = -1;
+        if (bestc[b] != 0xffffffffu) {
+            const unsigned r = bestc[b] & 15u;
+            idx = (int)((bestc[b] >> 4) * 32u + (r & 3u) + 8u * (r >> 2) + 4u * (unsigned)h);
+        }
+        const float od = __shfl_xor(bestd[b], 32);
+        const int oi = __shfl_xor(idx, 32);
+        float fd = bestd[b];
+        int fi = idx;
+        if (od < fd || (od == fd && (unsigned)oi < (unsigned)fi)) {
+            fd = od;
+            fi = oi;
+        }
+        const long r = row0 + 32 * b + j;
+        if (h == 0 && r < n) {
+            ids[r] = (long)fi;
+            if (dist) dist[r] = fd;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Any d (v1 fallback: scalar fmaf chains, one thread per row, centroids and norms from the same
+// image so the arithmetic is the same as the MFMA path).  Used when d is not 64 or 128.
+__global__ void __launch_bounds__(WG)
+assign_generic_kernel(const float* __restrict__ X, long n, int d, const float* __restrict__ C,
+                      const float* __restrict__ cn, int k, long* __restrict__ ids,
+                      float* __restrict__ dist) {
+    const long i = (long)blockIdx.x * WG + threadIdx.x;
+    if (i >= n) return;
+    const float* xi = X + i * d;
+    float xn = 0.0f;
+    for (int f = 0; f < d; f++) xn = __builtin_fmaf(xi[f], xi[f], xn);
+    float best = __builtin_inff();
+    long bi = -1;
+    for (int c = 0; c < k; c++) {
+        const float* cc = C + (size_t)c * d;
+        float ip = 0.0f;
+        for (int f = 0; f < d; f++) ip = __builtin_fmaf(xi[f], cc[f], ip);
+        float dis = __builtin_fmaf(-2.0f, ip, xn + cn[c]);
+        dis = __builtin_fmaxf(dis, 0.0f);
+        if (dis < best) {
+            best = dis;
+            bi = c;
+        }
+    }
+    ids[i] = bi;
+    if (dist) dist[i] = best;
+}
+
+__global__ void __launch_bounds__(WG) row_sqnorm_kernel(const float* __restrict__ C, int k, int d,
+                                                        float* __restrict__ cn) {
+    const int c = blockIdx.x * WG + threadIdx.x;
+    if (c >= k) return;
+    float s = 0.0f;
+    for (int f = 0; f < d; f++) s = __builtin_fmaf(C[(size_t)c * d + f], C[(size_t)c * d + f], s);
+    cn[c] = s;
+}
+
+// faiss exhaustive_L2sqr_seq (n < distance_compute_blas_threshold = 20): direct sum (x-c)^2.
+__global__ void assign_small_kernel(const float* __restrict__ X, int n, int d,
+                                    const float* __restrict__ C, int k, long* __restrict__ ids,
+                                    float* __restrict__ dist) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float best = __builtin_inff();
+    long bi = -1;
+    for (int c = 0; c < k; c++) {
+        float acc = 0.0f;
+        for (int f = 0; f < d; f++) {
+            const float df = X[(size_t)i * d + f] - C[(size_t)c * d + f];
+            acc = __builtin_fmaf(df, df, acc);
+        }
+        if (acc < best) {
+            best = acc;
+            bi = c;
+        }
+    }
+    ids[i] = bi;
+    if (dist) dist[i] = best;
+}
+
+template <int D, int NB>
+int launch_mfma(const float* x, int64_t n, const float* img, int ntiles, int64_t* ids, float* dist,
+                hipStream_t stream) {
+    const size_t lds = 2 * sizeof(float) * tile_floats(D);
+    const int64_t rows_per_wg = 4 * 32 * NB;
+    const int64_t grid = (n + rows_per_wg - 1) / rows_per_wg;
+    static bool attr_set = false;
+    if (!attr_set) {
+        AT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&assign_mfma_kernel<D, NB>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((assign_mfma_kernel<D, NB>), dim3((unsigned)grid), dim3(WG), lds, stream, x,
+                       (long)n, img, ntiles, reinterpret_cast<long*>(ids), dist);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}
+
+}  // namespace
+
+extern "C" int at_assign_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
+                             int64_t* ids, float* dist, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AT_REQUIRE(ctx, "at_assign_f32: ctx is null");
+    AT_REQUIRE(n >= 0 && d > 0 && k > 0, "at_assign_f32: bad sizes n=%lld d=%d k=%d", (long long)n, d, k);
+    if (n == 0) return AT_OK;
+    AT_REQUIRE(x && c && ids, "at_assign_f32: null pointer");
+    AT_REQUIRE(k <= (1 << 24), "at_assign_f32: k=%d too large", k);
+    AT_HIP(hipSetDevice(ctx->device));
+
+    if (n < 20) {
+        hipLaunchKernelGGL(assign_small_kernel, dim3(1), dim3(32), 0, stream, x, (int)n, d, c, k,
+                           reinterpret_cast<long*>(ids), dist);
+        AT_LAUNCH_CHECK();
+        return AT_OK;
+    }
+
+    if (d == 64 || d == 128) {
+        AT_REQUIRE(at_aligned16(x), "at_assign_f32: x must be 16-byte aligned");
+        const int ntiles = (k + CT - 1) / CT;
+        const size_t img_bytes = sizeof(float) * (size_t)ntiles * tile_floats(d);
+        float* img = static_cast<float*>(at_ws(ctx, WS_CENT_IMG, img_bytes, stream));
+        if (!img) return AT_E_NOMEM;
+        hipLaunchKernelGGL(prep_centroids_kernel, dim3(ntiles), dim3(WG), 0, stream, c, k, d, d, img);
+        AT_LAUNCH_CHECK();
+        if (d == 64) return launch_mfma<64, 2>(x, n, img, ntiles, ids, dist, stream);
+        return launch_mfma<128, 1>(x, n, img, ntiles, ids, dist, stream);
+    }
+
+    float* cn = static_cast<float*>(at_ws(ctx, WS_CENT_IMG, sizeof(float) * (size_t)k, stream));
+    if (!cn) return AT_E_NOMEM;
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((k + WG - 1) / WG), dim3(WG), 0, stream, c, k, d, cn);
+    AT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(assign_generic_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0,
+                       stream, x, (long)n, d, c, cn, k, reinterpret_cast<long*>(ids), dist);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}

@@ -1,0 +1,59 @@
+// at_internal.h -- shared by the translation units of libaudio_tokens_amd.so (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/audio_tokens_amd.h"
+
+// Workspace slots of a context (grown on demand, never shrunk).
+enum at_ws_slot {
+    WS_CENT_IMG = 0,   // assign: tiled/swizzled centroid image + |c|^2
+    WS_SORT_KEYS_A,    // centroid_accum: keys / values, double buffered, + rocprim temp storage
+    WS_SORT_KEYS_B,
+    WS_SORT_VALS_A,
+    WS_SORT_VALS_B,
+    WS_SORT_TMP,
+    WS_SEG_OFFSETS,    // centroid_accum: k+1 segment starts
+    WS_REDUCE,         // at_sum_f32 / at_any_nonfinite partials
+    WS_LOGMEL_FB,      // log-mel: banded filterbank tables
+    WS_NSLOTS
+};
+
+struct at_ctx {
+    int device;
+    void* ws[WS_NSLOTS];
+    size_t ws_bytes[WS_NSLOTS];
+    // cached description of what WS_LOGMEL_FB currently holds
+    int fb_sr, fb_nfft, fb_nmels;
+    const float* fb_user;
+};
+
+int at_fail(int code, const char* fmt, ...);
+// Returns a device buffer of at least `bytes` for `slot` (contents undefined after growth).
+void* at_ws(at_ctx* ctx, int slot, size_t bytes, hipStream_t stream);
+
+#define AT_HIP(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return at_fail(AT_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                           __FILE__, __LINE__);                                            \
+    } while (0)
+
+#define AT_LAUNCH_CHECK()                                                                  \
+    do {                                                                                   \
+        hipError_t e_ = hipGetLastError();                                                 \
+        if (e_ != hipSuccess)                                                              \
+            return at_fail(AT_E_HIP, "kernel launch failed: %s (%s:%d)",                   \
+                           hipGetErrorString(e_), __FILE__, __LINE__);                     \
+    } while (0)
+
+#define AT_REQUIRE(cond, ...)                                  \
+    do {                                                       \
+        if (!(cond)) return at_fail(AT_E_INVALID, __VA_ARGS__); \
+    } while (0)
+
+static inline bool at_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

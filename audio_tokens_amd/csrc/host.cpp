@@ -1,0 +1,204 @@
+// host.cpp -- context, error reporting and the host-side (sequential, RNG-driven) pieces of the
+// FAISS clustering recipe that have no business on the GPU.
+//
+// Reference call sites replaced (paths in danavery/audio-tokens):
+//   processors/cluster_creator.py:42-56   faiss.Kmeans.train -> Clustering::train_encoded:
+//       subsample_training_set / centroid init  -> at_rand_perm_mt19937
+//       split_clusters                          -> at_split_clusters_host
+//   processors/spectrogram_generator.py:28-33  MelSpectrogram's mel filterbank -> at_mel_filterbank_host
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "at_internal.h"
+
+static thread_local std::string g_last_error;
+
+int at_fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+extern "C" {
+
+int at_version(void) { return AT_VERSION; }
+
+const char* at_last_error(void) { return g_last_error.c_str(); }
+
+int at_create(int device, at_ctx** out) {
+    AT_REQUIRE(out != nullptr, "at_create: out is null");
+    int ndev = 0;
+    AT_HIP(hipGetDeviceCount(&ndev));
+    AT_REQUIRE(device >= 0 && device < ndev, "at_create: device %d out of range (%d visible)",
+               device, ndev);
+    hipDeviceProp_t prop;
+    AT_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return at_fail(AT_E_INVALID, "at_create: device %d is %s; this library is built for gfx950 only",
+                       device, prop.gcnArchName);
+    at_ctx* c = new (std::nothrow) at_ctx();
+    if (!c) return at_fail(AT_E_NOMEM, "at_create: out of host memory");
+    std::memset(c, 0, sizeof *c);
+    c->device = device;
+    *out = c;
+    return AT_OK;
+}
+
+void at_destroy(at_ctx* ctx) {
+    if (!ctx) return;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < WS_NSLOTS; i++)
+        if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+    (void)hipSetDevice(prev);
+    delete ctx;
+}
+
+int64_t at_workspace_bytes(const at_ctx* ctx) {
+    if (!ctx) return 0;
+    size_t t = 0;
+    for (int i = 0; i < WS_NSLOTS; i++) t += ctx->ws_bytes[i];
+    return (int64_t)t;
+}
+
+}  // extern "C"
+
+void* at_ws(at_ctx* ctx, int slot, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) bytes = 16;
+    if (ctx->ws_bytes[slot] >= bytes) return ctx->ws[slot];
+    // Work already queued on `stream` may still read the old buffer: drain before freeing.
+    if (ctx->ws[slot]) {
+        if (hipStreamSynchronize(stream) != hipSuccess) return nullptr;
+        (void)hipFree(ctx->ws[slot]);
+        ctx->ws[slot] = nullptr;
+        ctx->ws_bytes[slot] = 0;
+    }
+    size_t want = bytes + bytes / 8;  // a little slack so slowly growing batches do not thrash
+    want = (want + 255) & ~size_t(255);
+    void* p = nullptr;
+    if (hipMalloc(&p, want) != hipSuccess) {
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            at_fail(AT_E_NOMEM, "workspace slot %d: hipMalloc(%zu) failed", slot, bytes);
+            return nullptr;
+        }
+        want = bytes;
+    }
+    ctx->ws[slot] = p;
+    ctx->ws_bytes[slot] = want;
+    if (slot == WS_LOGMEL_FB) { ctx->fb_sr = ctx->fb_nfft = ctx->fb_nmels = 0; ctx->fb_user = nullptr; }
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// faiss utils/random.cpp: RandomGenerator wraps std::mt19937; rand_int(max) = mt() % max;
+// rand_float() = mt() / float(mt.max()).
+namespace {
+struct FaissRng {
+    std::mt19937 mt;
+    explicit FaissRng(int64_t seed) : mt((unsigned int)seed) {}
+    int rand_int(int max) { return (int)(mt() % (unsigned long)max); }
+    float rand_float() { return mt() / float(mt.max()); }
+};
+}  // namespace
+
+extern "C" {
+
+int at_rand_perm_mt19937(int64_t n, int64_t seed, int32_t* perm) {
+    AT_REQUIRE(n >= 0 && n <= INT32_MAX, "at_rand_perm_mt19937: n=%lld out of range", (long long)n);
+    AT_REQUIRE(perm != nullptr || n == 0, "at_rand_perm_mt19937: perm is null");
+    for (int64_t i = 0; i < n; i++) perm[i] = (int32_t)i;
+    FaissRng rng(seed);
+    for (int64_t i = 0; i + 1 < n; i++) {
+        int64_t other = i + rng.rand_int((int)(n - i));
+        std::swap(perm[i], perm[other]);
+    }
+    return AT_OK;
+}
+
+int at_rand_perm_prefix_mt19937(int64_t n, int64_t seed, int64_t m, int32_t* prefix) {
+    AT_REQUIRE(n >= 0 && n <= INT32_MAX && m >= 0 && m <= n, "at_rand_perm_prefix_mt19937: bad sizes n=%lld m=%lld",
+               (long long)n, (long long)m);
+    AT_REQUIRE(prefix != nullptr || m == 0, "at_rand_perm_prefix_mt19937: prefix is null");
+    // Step i of the shuffle swaps position i with a position >= i, so positions < m are final
+    // after step m-1.  The full-length array is still needed as the pool being drawn from.
+    std::vector<int32_t> pool((size_t)n);
+    for (int64_t i = 0; i < n; i++) pool[i] = (int32_t)i;
+    FaissRng rng(seed);
+    for (int64_t i = 0; i < m && i + 1 < n; i++) {
+        int64_t other = i + rng.rand_int((int)(n - i));
+        std::swap(pool[i], pool[other]);
+    }
+    for (int64_t i = 0; i < m; i++) prefix[i] = pool[i];
+    return AT_OK;
+}
+
+int64_t at_num_frames(int64_t L, int hop) { return hop > 0 ? 1 + L / hop : 0; }
+
+int at_mel_filterbank_host(int sample_rate, int n_fft, int n_mels, float* fb) {
+    AT_REQUIRE(fb && sample_rate > 0 && n_fft >= 2 && n_mels >= 1, "at_mel_filterbank_host: bad arguments");
+    const int n_freqs = n_fft / 2 + 1;
+    const double f_max = (double)(sample_rate / 2);  // torchaudio: float(sample_rate // 2)
+    auto to_mel = [](double f) { return 2595.0 * std::log10(1.0 + f / 700.0); };
+    auto to_hz = [](double m) { return 700.0 * (std::pow(10.0, m / 2595.0) - 1.0); };
+    std::vector<double> edge(n_mels + 2);
+    const double m_lo = to_mel(0.0), m_hi = to_mel(f_max);
+    for (int i = 0; i < n_mels + 2; i++) edge[i] = to_hz(m_lo + (m_hi - m_lo) * i / (n_mels + 1));
+    for (int f = 0; f < n_freqs; f++) {
+        const double hz = f_max * f / (n_freqs - 1);
+        for (int m = 0; m < n_mels; m++) {
+            const double rise = (hz - edge[m]) / (edge[m + 1] - edge[m]);
+            const double fall = (edge[m + 2] - hz) / (edge[m + 2] - edge[m + 1]);
+            const double tri = std::fmin(rise, fall);
+            fb[(size_t)f * n_mels + m] = tri > 0.0 ? (float)tri : 0.0f;
+        }
+    }
+    return AT_OK;
+}
+
+int at_split_clusters_host(int d, int k, int64_t n, float* hassign, float* centroids, int* nsplit) {
+    AT_REQUIRE(hassign && centroids && d > 0 && k > 0, "at_split_clusters_host: bad arguments");
+    constexpr double kEps = 1.0 / 1024.0;
+    FaissRng rng(1234);
+    int count = 0;
+    const float denom = (float)(n - k);
+    for (int ci = 0; ci < k; ci++) {
+        if (hassign[ci] != 0.0f) continue;
+        // walk the clusters cyclically until one accepts with probability (size-1)/(n-k)
+        int donor = 0;
+        while (true) {
+            const float p = (float)((hassign[donor] - 1.0) / denom);
+            if (rng.rand_float() < p) break;
+            donor = (donor + 1) % k;
+        }
+        float* dst = centroids + (size_t)ci * d;
+        float* src = centroids + (size_t)donor * d;
+        std::memcpy(dst, src, sizeof(float) * (size_t)d);
+        for (int j = 0; j < d; j++) {
+            const double up = 1.0 + kEps, down = 1.0 - kEps;
+            if ((j & 1) == 0) {
+                dst[j] = (float)(dst[j] * up);
+                src[j] = (float)(src[j] * down);
+            } else {
+                dst[j] = (float)(dst[j] * down);
+                src[j] = (float)(src[j] * up);
+            }
+        }
+        hassign[ci] = hassign[donor] / 2;
+        hassign[donor] -= hassign[ci];
+        count++;
+    }
+    if (nsplit) *nsplit = count;
+    return AT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,327 @@
+// kmeans.hip -- the non-GEMM half of one Lloyd iteration on gfx950.
+//
+// Replaces, inside faiss.Kmeans.train (processors/cluster_creator.py:42-56 of danavery/audio-tokens):
+//   subsample_training_set's row copy      -> at_gather_rows_f32
+//   compute_centroids (accumulate)         -> at_centroid_accum_f32
+//   compute_centroids (1/count scaling)    -> at_centroid_finalize_f32   (+ data-parallel combine)
+//   the objective  sum_i dis[i]            -> at_sum_f32
+//   the isfinite() scan of the input       -> at_any_nonfinite_f32
+//
+// All of these are HBM-bound passes over [n][d] fp32 rows (4d+8 B per point per iteration).
+//
+// compute_centroids must reproduce what FAISS's owning thread produces: the members of a cluster
+// are added in ASCENDING point index with fp32 adds.  That order is made explicit here: a stable
+// radix sort of (assignment, point index) pairs (rocPRIM) yields every cluster's member list in
+// ascending index; one wavefront then walks one list, lanes across the feature axis, so each
+// row is one coalesced 4d-byte read and the adds are sequential per (cluster, feature) exactly as
+// on the CPU.  No float atomics anywhere: results are bitwise reproducible.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "at_internal.h"
+
+namespace {
+
+constexpr int WG = 256;
+
+__global__ void __launch_bounds__(WG) gather_rows_kernel(const float* __restrict__ x, int d4,
+                                                         const int32_t* __restrict__ idx, long m,
+                                                         float* __restrict__ out) {
+    // one 16-byte chunk per thread; consecutive threads walk one row, then the next
+    const long e = (long)blockIdx.x * WG + threadIdx.x;
+    if (e >= m * d4) return;
+    const long r = e / d4;
+    const int c = (int)(e - r * d4);
+    const float4* src = reinterpret_cast<const float4*>(x) + (long)idx[r] * d4 + c;
+    reinterpret_cast<float4*>(out)[e] = *src;
+}
+
+__global__ void __launch_bounds__(WG) gather_rows_scalar_kernel(const float* __restrict__ x, int d,
+                                                                const int32_t* __restrict__ idx,
+                                                                long m, float* __restrict__ out) {
+    const long e = (long)blockIdx.x * WG + threadIdx.x;
+    if (e >= m * d) return;
+    const long r = e / d;
+    const int c = (int)(e - r * d);
+    out[e] = x[(long)idx[r] * d + c];
+}
+
+__global__ void __launch_bounds__(WG) make_keys_kernel(const long* __restrict__ ids, long n, int k,
+                                                       uint32_t* __restrict__ keys,
+                                                       uint32_t* __restrict__ vals) {
+    const long i = (long)blockIdx.x * WG + threadIdx.x;
+    if (i >= n) return;
+    long c = ids[i];
+    // an id outside [0, k) (e.g. -1 from an all-NaN row) is parked in a trailing bucket that no
+    // centroid reads
+    keys[i] = (c >= 0 && c < k) ? (uint32_t)c : (uint32_t)k;
+    vals[i] = (uint32_t)i;
+}
+
+// offsets[c] = first position p in the sorted key array with keys[p] >= c, for c in [0, k].
+__global__ void __launch_bounds__(WG) segment_offsets_kernel(const uint32_t* __restrict__ keys, long n,
+                                                             int k, uint32_t* __restrict__ offsets) {
+    const int c = blockIdx.x * WG + threadIdx.x;
+    if (c > k) return;
+    long lo = 0, hi = n;
+    while (lo < hi) {
+        const long mid = (lo + hi) >> 1;
+        if (keys[mid] < (uint32_t)c) lo = mid + 1; else hi = mid;
+    }
+    offsets[c] = (uint32_t)lo;
+}
+
+// One wavefront per (cluster, 64*VEC-feature slab).  Lane owns VEC consecutive features.
+template <int VEC>
+__global__ void __launch_bounds__(WG) centroid_accum_kernel(const float* __restrict__ x, int d,
+                                                            const uint32_t* __restrict__ order,
+                                                            const uint32_t* __restrict__ offsets,
+                                                            int k, int slabs,
+                                                            float* __restrict__ sums,
+                                                            float* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const long w = (long)blockIdx.x * (WG / 64) + (threadIdx.x >> 6);
+    if (w >= (long)k * slabs) return;
+    const int c = (int)(w / slabs);
+    const int slab = (int)(w - (long)c * slabs);
+    const int f0 = (slab * 64 + lane) * VEC;
+    const bool live = f0 < d;  // d is a multiple of VEC
+    const uint32_t beg = offsets[c], end = offsets[c + 1];
+
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) acc[v] = 0.0f;
+
+    for (uint32_t base = beg; base < end; base += 64) {
+        const uint32_t cnt = min(64u, end - base);
+        const uint32_t mine = lane < cnt ? order[base + lane] : 0u;
+        for (uint32_t m = 0; m < cnt; m += 8) {
+            float t[8][VEC];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t src = __builtin_amdgcn_readlane(mine, (m + u) & 63);
+                const bool ok = (m + u < cnt) && live;
+                if constexpr (VEC == 4) {
+                    float4 q = ok ? *reinterpret_cast<const float4*>(x + (size_t)src * d + f0)
+                                  : make_float4(0, 0, 0, 0);
+                    t[u][0] = q.x; t[u][1] = q.y; t[u][2] = q.z; t[u][3] = q.w;
+                } else if constexpr (VEC == 2) {
+                    float2 q = ok ? *reinterpret_cast<const float2*>(x + (size_t)src * d + f0)
+                                  : make_float2(0, 0);
+                    t[u][0] = q.x; t[u][1] = q.y;
+                } else {
+                    t[u][0] = ok ? x[(size_t)src * d + f0] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (m + u < cnt) {  // wave-uniform: the tail adds nothing at all
+#pragma unroll
+                    for (int v = 0; v < VEC; v++) acc[v] += t[u][v];
+                }
+            }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int v = 0; v < VEC; v++) sums[(size_t)c * d + f0 + v] = acc[v];
+    }
+    if (slab == 0 && lane == 0) counts[c] = (float)(end - beg);
+}
+
+__global__ void __launch_bounds__(WG) centroid_finalize_kernel(const float* __restrict__ sums_parts,
+                                                               long sums_stride,
+                                                               const float* __restrict__ counts_parts,
+                                                               long counts_stride, int n_parts, int k,
+                                                               int d,
+                                                               float* __restrict__ cent,
+                                                               float* __restrict__ hassign) {
+    const long e = (long)blockIdx.x * WG + threadIdx.x;
+    if (e >= (long)k * d) return;
+    const int c = (int)(e / d);
+    float cnt = 0.0f, tot = 0.0f;
+    for (int p = 0; p < n_parts; p++) {
+        cnt += counts_parts[p * counts_stride + c];
+        tot += sums_parts[p * sums_stride + e];
+    }
+    float out = 0.0f;
+    if (cnt != 0.0f) {
+        const float inv = 1.0f / cnt;  // IEEE division, then one multiply: faiss' "norm = 1 / hassign"
+        out = tot * inv;
+    }
+    cent[e] = out;
+    if (e == (long)c * d) hassign[c] = cnt;
+}
+
+// ---- fixed-tree reductions ---------------------------------------------------------------------
+constexpr int RED_BLOCKS = 1024;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+
+__global__ void __launch_bounds__(WG) sum_partial_kernel(const float* __restrict__ v, long n,
+                                                         double* __restrict__ partial) {
+    __shared__ double sh[WG / 64];
+    double acc = 0.0;
+    for (long i = (long)blockIdx.x * WG + threadIdx.x; i < n; i += (long)gridDim.x * WG) acc += (double)v[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ void __launch_bounds__(WG) sum_final_kernel(const double* __restrict__ partial, int m,
+                                                       double* __restrict__ out) {
+    __shared__ double sh[WG / 64];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < m; i += WG) acc += partial[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ void __launch_bounds__(WG) nonfinite_kernel(const float* __restrict__ v, long n,
+                                                       int32_t* __restrict__ flag) {
+    bool bad = false;
+    for (long i = (long)blockIdx.x * WG + threadIdx.x; i < n; i += (long)gridDim.x * WG) {
+        const uint32_t bits = __float_as_uint(v[i]);
+        bad |= (bits & 0x7f800000u) == 0x7f800000u;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+}  // namespace
+
+extern "C" {
+
+int at_gather_rows_f32(at_ctx* ctx, const float* x, int d, const int32_t* idx, int64_t m, float* out,
+                       void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AT_REQUIRE(ctx, "at_gather_rows_f32: ctx is null");
+    AT_REQUIRE(m >= 0 && d > 0, "at_gather_rows_f32: bad sizes");
+    if (m == 0) return AT_OK;
+    AT_REQUIRE(x && idx && out, "at_gather_rows_f32: null pointer");
+    AT_HIP(hipSetDevice(ctx->device));
+    if (d % 4 == 0 && at_aligned16(x) && at_aligned16(out)) {
+        const long total = m * (d / 4);
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + WG - 1) / WG)), dim3(WG), 0,
+                           stream, x, d / 4, idx, (long)m, out);
+    } else {
+        const long total = m * d;
+        hipLaunchKernelGGL(gather_rows_scalar_kernel, dim3((unsigned)((total + WG - 1) / WG)), dim3(WG),
+                           0, stream, x, d, idx, (long)m, out);
+    }
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}
+
+int at_centroid_accum_f32(at_ctx* ctx, const float* x, int64_t n, int d, const int64_t* ids, int k,
+                          float* sums, float* counts, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AT_REQUIRE(ctx, "at_centroid_accum_f32: ctx is null");
+    AT_REQUIRE(n >= 0 && n < (int64_t)UINT32_MAX && d > 0 && k > 0 && k < (1 << 30),
+               "at_centroid_accum_f32: bad sizes n=%lld d=%d k=%d", (long long)n, d, k);
+    AT_REQUIRE(sums && counts && (n == 0 || (x && ids)), "at_centroid_accum_f32: null pointer");
+    AT_HIP(hipSetDevice(ctx->device));
+
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    uint32_t* keys_a = static_cast<uint32_t*>(at_ws(ctx, WS_SORT_KEYS_A, nn * 4, stream));
+    uint32_t* keys_b = static_cast<uint32_t*>(at_ws(ctx, WS_SORT_KEYS_B, nn * 4, stream));
+    uint32_t* vals_a = static_cast<uint32_t*>(at_ws(ctx, WS_SORT_VALS_A, nn * 4, stream));
+    uint32_t* vals_b = static_cast<uint32_t*>(at_ws(ctx, WS_SORT_VALS_B, nn * 4, stream));
+    uint32_t* offsets = static_cast<uint32_t*>(at_ws(ctx, WS_SEG_OFFSETS, ((size_t)k + 2) * 4, stream));
+    if (!keys_a || !keys_b || !vals_a || !vals_b || !offsets) return AT_E_NOMEM;
+
+    const uint32_t* order = vals_a;
+    const uint32_t* sorted_keys = keys_a;
+    if (n > 0) {
+        hipLaunchKernelGGL(make_keys_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, stream,
+                           reinterpret_cast<const long*>(ids), (long)n, k, keys_a, vals_a);
+        AT_LAUNCH_CHECK();
+        unsigned bits = 1;
+        while ((1u << bits) <= (unsigned)k) bits++;  // keys take values 0..k
+        rocprim::double_buffer<uint32_t> kb(keys_a, keys_b);
+        rocprim::double_buffer<uint32_t> vb(vals_a, vals_b);
+        size_t tmp_bytes = 0;
+        AT_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kb, vb, (size_t)n, 0, bits, stream));
+        void* tmp = at_ws(ctx, WS_SORT_TMP, tmp_bytes, stream);
+        if (!tmp) return AT_E_NOMEM;
+        AT_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, kb, vb, (size_t)n, 0, bits, stream));
+        order = vb.current();
+        sorted_keys = kb.current();
+    }
+    hipLaunchKernelGGL(segment_offsets_kernel, dim3((k + 1 + WG - 1) / WG), dim3(WG), 0, stream,
+                       sorted_keys, (long)n, k, offsets);
+    AT_LAUNCH_CHECK();
+
+    const bool al = at_aligned16(x);
+    int vec = 1;
+    if (d % 4 == 0 && d >= 256 && al) vec = 4;
+    else if (d % 2 == 0 && d >= 128 && al) vec = 2;
+    const int slabs = (d + 64 * vec - 1) / (64 * vec);
+    const long waves = (long)k * slabs;
+    const dim3 grid((unsigned)((waves + WG / 64 - 1) / (WG / 64)));
+    if (vec == 4)
+        hipLaunchKernelGGL(centroid_accum_kernel<4>, grid, dim3(WG), 0, stream, x, d, order, offsets, k,
+                           slabs, sums, counts);
+    else if (vec == 2)
+        hipLaunchKernelGGL(centroid_accum_kernel<2>, grid, dim3(WG), 0, stream, x, d, order, offsets, k,
+                           slabs, sums, counts);
+    else
+        hipLaunchKernelGGL(centroid_accum_kernel<1>, grid, dim3(WG), 0, stream, x, d, order, offsets, k,
+                           slabs, sums, counts);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}
+
+int at_centroid_finalize_f32(at_ctx* ctx, const float* sums_parts, int64_t sums_part_stride,
+                             const float* counts_parts, int64_t counts_part_stride, int n_parts,
+                             int k, int d, float* centroids, float* hassign, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AT_REQUIRE(ctx, "at_centroid_finalize_f32: ctx is null");
+    AT_REQUIRE(n_parts >= 1 && k > 0 && d > 0, "at_centroid_finalize_f32: bad sizes");
+    AT_REQUIRE(sums_parts && counts_parts && centroids && hassign, "at_centroid_finalize_f32: null pointer");
+    AT_HIP(hipSetDevice(ctx->device));
+    const long total = (long)k * d;
+    hipLaunchKernelGGL(centroid_finalize_kernel, dim3((unsigned)((total + WG - 1) / WG)), dim3(WG), 0,
+                       stream, sums_parts, (long)sums_part_stride, counts_parts,
+                       (long)counts_part_stride, n_parts, k, d, centroids, hassign);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}
+
+int at_sum_f32(at_ctx* ctx, const float* v, int64_t n, double* out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AT_REQUIRE(ctx && out && n >= 0 && (n == 0 || v), "at_sum_f32: bad arguments");
+    AT_HIP(hipSetDevice(ctx->device));
+    double* partial = static_cast<double*>(at_ws(ctx, WS_REDUCE, RED_BLOCKS * sizeof(double), stream));
+    if (!partial) return AT_E_NOMEM;
+    int blocks = (int)((n + WG - 1) / WG);
+    if (blocks > RED_BLOCKS) blocks = RED_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sum_partial_kernel, dim3(blocks), dim3(WG), 0, stream, v, (long)n, partial);
+    AT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(WG), 0, stream, partial, blocks, out);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}
+
+int at_any_nonfinite_f32(at_ctx* ctx, const float* v, int64_t n, int32_t* flag, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AT_REQUIRE(ctx && flag && n >= 0 && (n == 0 || v), "at_any_nonfinite_f32: bad arguments");
+    AT_HIP(hipSetDevice(ctx->device));
+    AT_HIP(hipMemsetAsync(flag, 0, sizeof(int32_t), stream));
+    if (n == 0) return AT_OK;
+    int blocks = (int)((n + WG - 1) / WG);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(nonfinite_kernel, dim3(blocks), dim3(WG), 0, stream, v, (long)n, flag);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}
+
+}  // extern "C"

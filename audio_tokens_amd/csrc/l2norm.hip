@@ -1,0 +1,73 @@
+// l2norm.hip -- row L2 normalisation with numpy's exact fp32 arithmetic (at_l2norm_rows_f32).
+//
+// Replaces ClusterCreator.normalize_vectors (processors/cluster_creator.py:64-66) and
+// SpecTokenizer.normalize_vectors (processors/spec_tokenizer.py:106-109):
+//     norms = np.linalg.norm(vectors, axis=1, keepdims=True);  vectors / (norms + 1e-10)
+// numpy evaluates this in fp32 as sqrt(add.reduce(x*x)) with its pairwise summation (8 running
+// sums over blocks of <= 128, combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), halves split at a
+// multiple of 8 above 128), then one add and one IEEE division per element.  The same order is
+// used here, so the result is bit-identical to numpy's.  HBM-bound: 8d bytes per row.
+//
+// Layout: a workgroup stages R rows in LDS (coalesced reads, row pitch d+1 so a row-per-thread
+// walk is bank-conflict free), R threads reduce one row each, then all threads divide and store
+// coalesced.
+#include "at_internal.h"
+#include "l2norm_core.h"
+
+namespace {
+
+constexpr int WG = 256;
+
+__global__ void __launch_bounds__(WG) l2norm_rows_kernel(const float* __restrict__ x, long n, int d,
+                                                         int rows_per_block, float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // R*(d+1) floats + R floats
+    const int R = rows_per_block;
+    const int pitch = d + 1;
+    float* den = sm + (size_t)R * pitch;
+    const long row0 = (long)blockIdx.x * R;
+    const int rows = (int)min((long)R, n - row0);
+    const long total = (long)rows * d;
+    const float* src = x + row0 * d;
+    for (long e = threadIdx.x; e < total; e += WG) {
+        const int r = (int)(e / d), c = (int)(e - (long)r * d);
+        sm[(size_t)r * pitch + c] = src[e];
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < rows; r += WG) {
+        den[r] = l2n::row_denominator(sm + (size_t)r * pitch, d, 1);
+    }
+    __syncthreads();
+    float* dst = y + row0 * d;
+    for (long e = threadIdx.x; e < total; e += WG) {
+        const int r = (int)(e / d), c = (int)(e - (long)r * d);
+        dst[e] = l2n::divide(sm[(size_t)r * pitch + c], den[r]);
+    }
+}
+
+}  // namespace
+
+extern "C" int at_l2norm_rows_f32(at_ctx* ctx, const float* x, int64_t n, int d, float* y,
+                                  void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AT_REQUIRE(ctx, "at_l2norm_rows_f32: ctx is null");
+    AT_REQUIRE(n >= 0 && d > 0, "at_l2norm_rows_f32: bad sizes");
+    if (n == 0) return AT_OK;
+    AT_REQUIRE(x && y, "at_l2norm_rows_f32: null pointer");
+    AT_REQUIRE(d <= 16384, "at_l2norm_rows_f32: d=%d not supported (max 16384)", d);
+    AT_HIP(hipSetDevice(ctx->device));
+    // rows per workgroup: as many as fit ~66 KB of LDS (2 workgroups per CU), at most 256
+    int R = 256;
+    while (R > 1 && (size_t)R * (d + 2) * sizeof(float) > 68 * 1024) R >>= 1;
+    const size_t lds = (size_t)R * (d + 2) * sizeof(float);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        AT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2norm_rows_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
+    }
+    const long blocks = (n + R - 1) / R;
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)blocks), dim3(WG), lds, stream, x, (long)n, d,
+                       R, y);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}

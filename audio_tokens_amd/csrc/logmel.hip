@@ -1,0 +1,243 @@
+// logmel.hip -- fused waveform -> STFT -> |.|^2 -> mel -> dB on gfx950 (at_logmel_f32).
+//
+// Replaces SpectrogramGenerator.generate_mel_spectrogram (processors/spectrogram_generator.py:
+// 123-126 of danavery/audio-tokens): torchaudio MelSpectrogram(sample_rate, n_mels, n_fft=512,
+// hop_length) with its defaults (center=True, reflect padding, periodic Hann, power=2, htk mel
+// scale, norm=None, f_min=0, f_max=sr//2) followed by AmplitudeToDB() (10*log10(max(x, 1e-10))).
+// Optionally emits frame-major rows and the row L2 normalisation the two consumers apply next
+// (cluster_creator.py:52,64-66; spec_tokenizer.py:76,106-109), which removes the reference's
+// transpose + normalise round trip through memory.
+//
+// One workgroup = FPB consecutive frames of one clip.  Their samples are read from HBM once,
+// coalesced, into LDS with the reflect padding applied on the way (every sample is shared by
+// n_fft/hop = 4 frames).  A frame is owned by 16 lanes (4 frames per wavefront): 16-point FFTs
+// in registers down the columns, one transpose through a conflict-free LDS tile, 16-point FFTs
+// along the rows, even/odd untangling to the 257 power bins (logmel_core.h), then the mel
+// filterbank as a banded dot product per filter (only the non-zero taps), 10*log10, and a staged
+// coalesced store.  Algorithmic HBM traffic: hop*4 bytes in + n_mels*4 bytes out per frame.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "at_internal.h"
+#include "l2norm_core.h"
+#include "logmel_core.h"
+
+namespace {
+
+using namespace logmel;
+
+constexpr int WG = 256;
+constexpr int TAB_WIN = 0, TAB_TW256 = 512, TAB_TW512 = 1024, TAB_FLOATS = 1536;
+
+struct LogmelParams {
+    const float* wave;
+    long n_clips, L, wave_stride;
+    int hop, T, n_mels, fpb;
+    const float* tabs;      // TAB_FLOATS floats: window, W256 twiddles, W512 twiddles
+    const int* fb_start;    // [n_mels]
+    const int* fb_len;      // [n_mels]
+    const int* fb_off;      // [n_mels] offset into fb_wts
+    const float* fb_wts;    // concatenated non-zero bands
+    float* out;
+    int frame_major, fuse_l2norm;
+};
+
+__global__ void __launch_bounds__(WG, 2) logmel_kernel(LogmelParams p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, grp = lane >> 4;
+    const int nsamp = (p.fpb - 1) * p.hop + NFFT;
+    const int opitch = p.n_mels + 1;
+
+    float* tabs = sm;                              // TAB_FLOATS
+    float* samp = tabs + TAB_FLOATS;               // nsamp (rounded up to 4)
+    float* work = samp + ((nsamp + 3) & ~3);       // 16 frames x FRAME_LDS_FLOATS
+    float* ostage = work + 16 * FRAME_LDS_FLOATS;  // fpb x opitch  (+ fpb denominators)
+
+    const long clip = blockIdx.y;
+    const int t0 = blockIdx.x * p.fpb;
+    const float* w = p.wave + clip * p.wave_stride;
+
+    for (int i = tid; i < TAB_FLOATS; i += WG) tabs[i] = p.tabs[i];
+    {
+        const long s0 = (long)t0 * p.hop - NFFT / 2;
+        for (int i = tid; i < nsamp; i += WG) {
+            long q = s0 + i;
+            if (q < 0) q = -q;                      // reflect, no edge repeat
+            if (q >= p.L) q = 2 * (p.L - 1) - q;
+            if (q < 0) q = 0;                       // only reachable for frames past T (never stored)
+            if (q >= p.L) q = p.L - 1;
+            samp[i] = w[q];
+        }
+    }
+    __syncthreads();
+
+    float* mybuf = work + (wave * 4 + grp) * FRAME_LDS_FLOATS;
+    const int n_mel_iter = (p.n_mels + 15) >> 4;
+    for (int pass = 0; pass * 16 < p.fpb; pass++) {
+        const int f = pass * 16 + wave * 4 + grp;   // frame within the workgroup
+        // every DS access below stays inside this frame's 16 lanes' private tile; a wavefront's
+        // LDS instructions execute in order, so no barrier is needed between the phases
+        phase1(l16, samp + f * p.hop, tabs + TAB_WIN, tabs + TAB_TW256, mybuf);
+        cpx z[16];
+        phase2(l16, mybuf, z);
+        phase3_publish(l16, z, mybuf);
+        float pw[16], p256 = 0.0f;
+        phase3_power(l16, z, mybuf, tabs + TAB_TW512, pw, p256);
+#pragma unroll
+        for (int e = 0; e < 16; e++) mybuf[l16 + 16 * e] = pw[e];
+        if (l16 == 0) mybuf[256] = p256;
+        for (int i = 0; i < n_mel_iter; i++) {
+            const int m = l16 + 16 * i;
+            if (m < p.n_mels) {
+                float s = mel_band(mybuf, p.fb_start[m], p.fb_len[m], p.fb_wts + p.fb_off[m]);
+                s = fmaxf(s, 1e-10f);
+                ostage[f * opitch + m] = 10.0f * log10f(s);
+            }
+        }
+    }
+    __syncthreads();
+
+    const int nf = min(p.fpb, p.T - t0);  // frames of this workgroup that exist
+    if (p.frame_major) {
+        float* den = ostage + p.fpb * opitch;
+        if (p.fuse_l2norm) {
+            for (int f = tid; f < nf; f += WG) den[f] = l2n::row_denominator(ostage + f * opitch, p.n_mels, 1);
+            __syncthreads();
+        }
+        float* dst = p.out + ((long)clip * p.T + t0) * p.n_mels;
+        const int total = nf * p.n_mels;
+        for (int e = tid; e < total; e += WG) {
+            const int f = e / p.n_mels, m = e - f * p.n_mels;
+            float v = ostage[f * opitch + m];
+            if (p.fuse_l2norm) v = l2n::divide(v, den[f]);
+            dst[e] = v;
+        }
+    } else {
+        float* dst = p.out + (long)clip * p.n_mels * p.T + t0;
+        const int total = p.n_mels * p.fpb;
+        for (int e = tid; e < total; e += WG) {
+            const int m = e / p.fpb, f = e - m * p.fpb;
+            if (f < nf) dst[(long)m * p.T + f] = ostage[f * opitch + m];
+        }
+    }
+}
+
+// Host side: window / twiddles / banded filterbank, uploaded once per (sr, n_mels, fb) change.
+int build_tables(at_ctx* ctx, int sample_rate, int n_mels, const float* fb_user_dev, hipStream_t stream,
+                 const float** tabs, const int** st, const int** ln, const int** of, const float** wt) {
+    const bool cached = ctx->ws[WS_LOGMEL_FB] && ctx->fb_sr == sample_rate && ctx->fb_nfft == NFFT &&
+                        ctx->fb_nmels == n_mels && ctx->fb_user == fb_user_dev;
+    std::vector<float> fb((size_t)NBIN * n_mels);
+    std::vector<int> start(n_mels), len(n_mels), off(n_mels);
+    std::vector<float> wts;
+    size_t bytes = 0;
+    char* base = nullptr;
+    if (!cached) {
+        if (fb_user_dev) {
+            AT_HIP(hipStreamSynchronize(stream));
+            AT_HIP(hipMemcpy(fb.data(), fb_user_dev, fb.size() * sizeof(float), hipMemcpyDeviceToHost));
+        } else {
+            int rc = at_mel_filterbank_host(sample_rate, NFFT, n_mels, fb.data());
+            if (rc) return rc;
+        }
+        for (int m = 0; m < n_mels; m++) {
+            int lo = NBIN, hi = -1;
+            for (int f = 0; f < NBIN; f++)
+                if (fb[(size_t)f * n_mels + m] != 0.0f) { lo = f < lo ? f : lo; hi = f; }
+            start[m] = hi < 0 ? 0 : lo;
+            len[m] = hi < 0 ? 0 : hi - lo + 1;
+            off[m] = (int)wts.size();
+            for (int f = start[m]; f < start[m] + len[m]; f++) wts.push_back(fb[(size_t)f * n_mels + m]);
+        }
+    }
+    // layout: [tabs TAB_FLOATS f32][start n_mels i32][len][off][wts ...]; worst case all bins per filter
+    const size_t cap = sizeof(float) * TAB_FLOATS + sizeof(int) * 3 * (size_t)n_mels +
+                       sizeof(float) * (size_t)NBIN * n_mels;
+    if (!cached) {
+        base = static_cast<char*>(at_ws(ctx, WS_LOGMEL_FB, cap, stream));
+        if (!base) return AT_E_NOMEM;
+        std::vector<float> t(TAB_FLOATS);
+        for (int i = 0; i < NFFT; i++) t[TAB_WIN + i] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * i / NFFT));
+        for (int j = 0; j < 256; j++) {
+            t[TAB_TW256 + 2 * j] = (float)std::cos(2.0 * M_PI * j / 256.0);
+            t[TAB_TW256 + 2 * j + 1] = (float)-std::sin(2.0 * M_PI * j / 256.0);
+            t[TAB_TW512 + 2 * j] = (float)std::cos(2.0 * M_PI * j / 512.0);
+            t[TAB_TW512 + 2 * j + 1] = (float)-std::sin(2.0 * M_PI * j / 512.0);
+        }
+        std::vector<char> blob(sizeof(float) * TAB_FLOATS + sizeof(int) * 3 * (size_t)n_mels +
+                               sizeof(float) * wts.size());
+        char* q = blob.data();
+        std::memcpy(q, t.data(), sizeof(float) * TAB_FLOATS); q += sizeof(float) * TAB_FLOATS;
+        std::memcpy(q, start.data(), sizeof(int) * n_mels); q += sizeof(int) * n_mels;
+        std::memcpy(q, len.data(), sizeof(int) * n_mels); q += sizeof(int) * n_mels;
+        std::memcpy(q, off.data(), sizeof(int) * n_mels); q += sizeof(int) * n_mels;
+        if (!wts.empty()) std::memcpy(q, wts.data(), sizeof(float) * wts.size());
+        bytes = blob.size();
+        AT_HIP(hipStreamSynchronize(stream));
+        AT_HIP(hipMemcpy(base, blob.data(), bytes, hipMemcpyHostToDevice));
+        ctx->fb_sr = sample_rate; ctx->fb_nfft = NFFT; ctx->fb_nmels = n_mels; ctx->fb_user = fb_user_dev;
+    } else {
+        base = static_cast<char*>(ctx->ws[WS_LOGMEL_FB]);
+    }
+    *tabs = reinterpret_cast<const float*>(base);
+    const int* ints = reinterpret_cast<const int*>(base + sizeof(float) * TAB_FLOATS);
+    *st = ints; *ln = ints + n_mels; *of = ints + 2 * n_mels;
+    *wt = reinterpret_cast<const float*>(ints + 3 * n_mels);
+    return AT_OK;
+}
+
+}  // namespace
+
+extern "C" int at_logmel_f32(at_ctx* ctx, const float* wave, int64_t n_clips, int64_t L,
+                             int64_t wave_stride, int sample_rate, int n_fft, int hop, int n_mels,
+                             const float* fb_or_null, float* out, int layout, int fuse_l2norm,
+                             void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AT_REQUIRE(ctx, "at_logmel_f32: ctx is null");
+    AT_REQUIRE(n_fft == NFFT, "at_logmel_f32: n_fft=%d not supported (this version: 512)", n_fft);
+    AT_REQUIRE(hop >= 1 && hop <= NFFT, "at_logmel_f32: hop=%d out of range [1, %d]", hop, NFFT);
+    AT_REQUIRE(n_mels >= 1 && n_mels <= 1024, "at_logmel_f32: n_mels=%d out of range", n_mels);
+    AT_REQUIRE(n_clips >= 0 && n_clips <= 65535 * 1024L, "at_logmel_f32: n_clips out of range");
+    AT_REQUIRE(L > NFFT / 2, "at_logmel_f32: clip length %lld must exceed n_fft/2 (reflect padding)", (long long)L);
+    AT_REQUIRE(wave_stride >= L, "at_logmel_f32: wave_stride < L");
+    AT_REQUIRE(layout == AT_LAYOUT_MEL_MAJOR || layout == AT_LAYOUT_FRAME_MAJOR, "at_logmel_f32: bad layout");
+    AT_REQUIRE(!fuse_l2norm || layout == AT_LAYOUT_FRAME_MAJOR, "at_logmel_f32: fuse_l2norm needs the frame-major layout");
+    if (n_clips == 0) return AT_OK;
+    AT_REQUIRE(wave && out, "at_logmel_f32: null pointer");
+    AT_HIP(hipSetDevice(ctx->device));
+
+    LogmelParams p;
+    int rc = build_tables(ctx, sample_rate, n_mels, fb_or_null, stream, &p.tabs, &p.fb_start, &p.fb_len,
+                          &p.fb_off, &p.fb_wts);
+    if (rc) return rc;
+    const int64_t T = at_num_frames(L, hop);
+    AT_REQUIRE(T < (1LL << 31), "at_logmel_f32: too many frames per clip");
+    p.wave = wave; p.n_clips = n_clips; p.L = L; p.wave_stride = wave_stride;
+    p.hop = hop; p.T = (int)T; p.n_mels = n_mels;
+    p.fpb = (31 * hop + NFFT) * 4 <= 20 * 1024 ? 32 : 16;
+    p.out = out; p.frame_major = layout == AT_LAYOUT_FRAME_MAJOR; p.fuse_l2norm = fuse_l2norm;
+
+    const int nsamp = (p.fpb - 1) * hop + NFFT;
+    const size_t lds = sizeof(float) * ((size_t)TAB_FLOATS + ((nsamp + 3) & ~3) + 16 * FRAME_LDS_FLOATS +
+                                        (size_t)p.fpb * (n_mels + 1) + p.fpb);
+    AT_REQUIRE(lds <= 160 * 1024, "at_logmel_f32: n_mels=%d needs %zu bytes of LDS", n_mels, lds);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        AT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&logmel_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
+    }
+    const unsigned gx = (unsigned)((T + p.fpb - 1) / p.fpb);
+    // gridDim.y is limited to 65535: sweep the clips in slabs
+    for (int64_t c0 = 0; c0 < n_clips; c0 += 65535) {
+        const unsigned gy = (unsigned)((n_clips - c0) < 65535 ? (n_clips - c0) : 65535);
+        LogmelParams q = p;
+        q.wave = wave + c0 * wave_stride;
+        q.out = out + c0 * (int64_t)n_mels * T;
+        hipLaunchKernelGGL(logmel_kernel, dim3(gx, gy), dim3(WG), lds, stream, q);
+        AT_LAUNCH_CHECK();
+    }
+    return AT_OK;
+}

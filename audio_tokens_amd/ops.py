@@ -1,0 +1,311 @@
+"""MI355X-native stand-ins for the three third-party operators the reference's stage classes call.
+
+    torchaudio.transforms.MelSpectrogram + AmplitudeToDB  ->  LogMelSpectrogram
+        (processors/spectrogram_generator.py:28-34,123-126 of danavery/audio-tokens)
+    faiss.Kmeans                                          ->  Kmeans
+        (processors/cluster_creator.py:42-56)
+    faiss.IndexFlatL2                                     ->  IndexFlatL2
+        (processors/spec_tokenizer.py:123-127, 77)
+
+Same constructor arguments, method names, return types and error behaviour as the originals for the
+subset the reference uses.  All arithmetic happens in libaudio_tokens_amd.so (HIP, gfx950); this
+file is the host-side orchestration: the FAISS training recipe (subsample permutation, random
+initialisation, 20 Lloyd iterations, empty-cluster repair) and, when torch.distributed is
+initialised and `distributed=True`, the data-parallel variant in which every rank owns a block of
+rows and the per-cluster partial sums/counts are exchanged once per iteration.
+"""
+from __future__ import annotations
+
+import sys
+import time
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .backend import default_backend
+
+__all__ = ["LogMelSpectrogram", "Kmeans", "IndexFlatL2", "normalize_rows"]
+
+
+def _is_host(x) -> bool:
+    return isinstance(x, np.ndarray) or (isinstance(x, torch.Tensor) and x.device.type == "cpu")
+
+
+def normalize_rows(x, backend=None):
+    """x / (||x||_2 + 1e-10) row-wise, bit-identical to the reference's numpy expression
+    (cluster_creator.py:64-66).  numpy in -> numpy out; device tensor in -> device tensor out."""
+    be = backend or default_backend()
+    host = _is_host(x)
+    y = be.l2norm_rows(x)
+    return be.to_host(y) if host else y
+
+
+class LogMelSpectrogram:
+    """MelSpectrogram(sample_rate, n_mels, n_fft, hop_length) followed by AmplitudeToDB(), fused.
+
+    __call__(waveform [..., L]) -> [..., n_mels, T] float32 in dB (torchaudio's layout)."""
+
+    def __init__(self, sample_rate=22050, n_fft=512, hop_length=128, n_mels=64, fb=None, backend=None):
+        self.sample_rate, self.n_fft, self.hop_length, self.n_mels = sample_rate, n_fft, hop_length, n_mels
+        self.backend = backend or default_backend()
+        self.fb = None if fb is None else self.backend._f32(fb)
+
+    def to(self, device):  # torchaudio-style chaining; the backend already pins the device
+        return self
+
+    def __call__(self, waveform):
+        be = self.backend
+        w = be._f32(waveform)
+        lead = w.shape[:-1]
+        out = be.logmel(w.reshape(-1, w.shape[-1]), self.sample_rate, self.n_fft, self.hop_length,
+                        self.n_mels, fb=self.fb)
+        return out.reshape(*lead, self.n_mels, out.shape[-1])
+
+    def frames(self, waveform, l2norm=False):
+        """[n_clips, L] -> frame-major [n_clips*T, n_mels] (optionally row-normalised): the matrix
+        ClusterCreator / SpecTokenizer build from the .npy files, without the round trip."""
+        be = self.backend
+        return be.logmel(be._f32(waveform), self.sample_rate, self.n_fft, self.hop_length, self.n_mels,
+                         fb=self.fb, frame_major=True, l2norm=l2norm)
+
+
+class _Dist:
+    """Thin view of torch.distributed for the sharded k-means (one process per GPU, RCCL)."""
+
+    def __init__(self, enabled, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.on = bool(enabled) and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.group = group
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.rank = dist.get_rank(group) if self.on else 0
+
+    def all_gather_sizes(self, n_loc, device):
+        if not self.on:
+            return [n_loc]
+        t = torch.tensor([n_loc], dtype=torch.int64, device=device)
+        out = torch.empty(self.world, dtype=torch.int64, device=device)
+        self.dist.all_gather_into_tensor(out, t, group=self.group)
+        return [int(v) for v in out.cpu()]
+
+    def any_flag(self, flag: bool, device) -> bool:
+        if not self.on:
+            return flag
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return bool(t.item())
+
+    def all_gather_parts(self, part):
+        """part [m] float32 -> [world, m], rank order."""
+        if not self.on:
+            return part.unsqueeze(0)
+        out = torch.empty((self.world, part.numel()), dtype=part.dtype, device=part.device)
+        self.dist.all_gather_into_tensor(out, part, group=self.group)
+        return out
+
+    def sum_bits(self, rows):
+        """Exact merge of float32 rows of which exactly one rank holds a non-zero copy."""
+        if not self.on:
+            return rows
+        bits = rows.view(torch.int32)
+        self.dist.all_reduce(bits, op=self.dist.ReduceOp.SUM, group=self.group)
+        return bits.view(torch.float32)
+
+    def sum_f64(self, v):
+        if self.on:
+            self.dist.all_reduce(v, op=self.dist.ReduceOp.SUM, group=self.group)
+        return v
+
+
+_PERM_CACHE: "OrderedDict[tuple, np.ndarray]" = OrderedDict()
+
+
+def _perm_prefix(be, n, seed, m):
+    """First m entries of faiss' rand_perm(n, seed).  A pure function of (n, seed, m): the batches
+    of one run all have the same n, so the few most recent results are kept."""
+    key = (int(n), int(seed), int(m))
+    hit = _PERM_CACHE.get(key)
+    if hit is not None:
+        _PERM_CACHE.move_to_end(key)
+        return hit
+    p = be.rand_perm_prefix(n, seed, m)
+    _PERM_CACHE[key] = p
+    while len(_PERM_CACHE) > 4:
+        _PERM_CACHE.popitem(last=False)
+    return p
+
+
+class Kmeans:
+    """faiss.Kmeans(d, k, niter=, verbose=, gpu=) for the reference's use (cluster_creator.py:42-48).
+
+    ClusteringParameters are FAISS's defaults: nredo=1, seed=1234, max_points_per_centroid=256,
+    min_points_per_centroid=39, no spherical / int / frozen centroids.  Each train() call is one
+    faiss Clustering::train: subsample to k*256 rows with rand_perm(n, seed), initialise from
+    `init_centroids` or from rand_perm(n_sub, seed+1), then niter x {nearest centroid, objective,
+    ascending-index centroid sums, 1/count, split_clusters}.
+
+    distributed=True (and torch.distributed initialised): `x` is this rank's block of the global
+    row-concatenation in rank order; the result is identical on every rank.
+    """
+
+    def __init__(self, d, k, niter=20, verbose=False, gpu=True, seed=1234, max_points_per_centroid=256,
+                 min_points_per_centroid=39, distributed=False, process_group=None, backend=None, **kwargs):
+        unsupported = {kk: v for kk, v in kwargs.items() if kk not in ("nredo",) or v != 1}
+        if unsupported:
+            raise NotImplementedError(f"Kmeans: unsupported ClusteringParameters {sorted(unsupported)}")
+        self.d, self.k, self.niter, self.verbose = int(d), int(k), int(niter), bool(verbose)
+        self.gpu = gpu  # accepted for signature compatibility; this implementation is GPU-only
+        self.seed = int(seed)
+        self.max_points_per_centroid = int(max_points_per_centroid)
+        self.min_points_per_centroid = int(min_points_per_centroid)
+        self.backend = backend or default_backend()
+        self._dist_enabled, self._group = distributed, process_group
+        self.centroids = None          # numpy [k, d] after train(), like faiss
+        self.centroids_device = None   # same, resident
+        self.obj = np.zeros(0, np.float32)
+        self.iteration_stats = []
+        self.index = None
+
+    # ------------------------------------------------------------------------------------
+    def train(self, x, init_centroids=None):
+        be = self.backend
+        k, d = self.k, self.d
+        dist = _Dist(self._dist_enabled, self._group)
+        if isinstance(x, np.ndarray):
+            assert x.flags.c_contiguous, "x must be C-contiguous"  # faiss asserts the same
+        x = be._f32(x)
+        assert x.dim() == 2 and x.shape[1] == d, f"expected [n, {d}], got {tuple(x.shape)}"
+        n_loc = x.shape[0]
+        sizes = dist.all_gather_sizes(n_loc, be.device)
+        off = sum(sizes[:dist.rank])
+        n = sum(sizes)
+        if n < k:
+            raise RuntimeError(f"Error: 'nx >= k' failed: Number of training points ({n}) should be at "
+                               f"least as large as number of clusters ({k})")
+        if dist.any_flag(be.any_nonfinite(x) if n_loc else False, be.device):
+            raise RuntimeError("Error: 'std::isfinite(x_in[i])' failed: input contains NaN's or Inf's")
+
+        # ---- subsample_training_set -------------------------------------------------------
+        if n > k * self.max_points_per_centroid:
+            ns = k * self.max_points_per_centroid
+            if self.verbose:
+                print(f"Sampling a subset of {ns} / {n} for training")
+            perm = _perm_prefix(be, n, self.seed, ns)
+            if dist.on:
+                mine = (perm >= off) & (perm < off + n_loc)
+                pos = np.flatnonzero(mine).astype(np.int64)      # subsample positions this rank owns
+                xs = be.gather_rows(x, (perm[mine] - off).astype(np.int32))
+            else:
+                pos = None
+                xs = be.gather_rows(x, perm)
+        else:
+            ns = n
+            if ns < k * self.min_points_per_centroid:
+                print(f"WARNING clustering {ns} points to {k} centroids: please provide at least "
+                      f"{k * self.min_points_per_centroid} training points", file=sys.stderr)
+            xs = x
+            pos = off + np.arange(n_loc, dtype=np.int64) if dist.on else None
+
+        def rows_at(positions):
+            """Rows of the (global) subsample at `positions` [m] -> device [m, d], on every rank."""
+            positions = np.asarray(positions, dtype=np.int64)
+            if not dist.on:
+                return be.gather_rows(xs, positions.astype(np.int32))
+            out = be.zeros((len(positions), d))
+            j = np.searchsorted(pos, positions)
+            ok = (j < len(pos))
+            ok[ok] &= pos[j[ok]] == positions[ok]
+            if ok.any():
+                out[torch.from_numpy(np.flatnonzero(ok)).to(be.device)] = be.gather_rows(xs, j[ok].astype(np.int32))
+            return dist.sum_bits(out)
+
+        self.iteration_stats = []
+        if ns == k:  # faiss corner case: the training set becomes the centroids
+            cent = rows_at(np.arange(k))
+            self.iteration_stats.append(dict(obj=0.0, time=0.0, time_search=0.0, imbalance_factor=1.0, nsplit=0))
+            return self._finish(cent)
+
+        if init_centroids is not None:
+            cent = be._f32(init_centroids).clone()
+            assert tuple(cent.shape) == (k, d), f"init_centroids must be [{k}, {d}]"
+        else:
+            cent = rows_at(_perm_prefix(be, ns, self.seed + 1, k))
+
+        # ---- Lloyd iterations -------------------------------------------------------------
+        hassign_host = be.host_staging((k,), torch.float32)
+        obj_host = be.host_staging((1,), torch.float64)
+        t0 = time.time()
+        t_search = 0.0
+        for it in range(self.niter):
+            ts = time.time()
+            ids, dis = be.assign(xs, cent)
+            obj = dist.sum_f64(be.sum_f64(dis))
+            part = be.centroid_accum(xs, ids, k)
+            parts = dist.all_gather_parts(part)
+            cent, hassign = be.centroid_finalize(parts, k, d)
+            hassign_host.copy_(hassign, non_blocking=True)
+            obj_host.copy_(obj, non_blocking=True)
+            be.synchronize()
+            t_search += time.time() - ts  # (the whole iteration is device work here)
+            h = hassign_host.numpy()
+            hd = h.astype(np.float64)
+            imbalance = float((hd * hd).sum() * k / (hd.sum() ** 2))
+            nsplit = 0
+            if (h == 0).any():
+                c_host = be.to_host(cent)
+                h_work = h.copy()
+                nsplit = be.split_clusters(h_work, c_host, ns)
+                cent = be.from_host(c_host)
+            st = dict(obj=float(np.float32(obj_host.item())), time=time.time() - t0, time_search=t_search,
+                      imbalance_factor=imbalance, nsplit=nsplit)
+            self.iteration_stats.append(st)
+            if self.verbose:
+                print(f"  Iteration {it} ({st['time']:.2f} s, search {st['time_search']:.2f} s): "
+                      f"objective={st['obj']:g} imbalance={imbalance:.3f} nsplit={nsplit}", flush=True)
+        self._last_assign = ids
+        return self._finish(cent)
+
+    def _finish(self, cent):
+        self.centroids_device = cent
+        self.centroids = self.backend.to_host(cent)
+        self.obj = np.array([s["obj"] for s in self.iteration_stats], dtype=np.float32)
+        self.index = IndexFlatL2(self.d, backend=self.backend)
+        self.index.add(cent)
+        return float(self.obj[-1]) if self.obj.size else 0.0
+
+
+class IndexFlatL2:
+    """faiss.IndexFlatL2(d) with add / search(x, 1) / reset / ntotal (spec_tokenizer.py:123-127,77)."""
+
+    def __init__(self, d, backend=None):
+        self.d = int(d)
+        self.backend = backend or default_backend()
+        self._c = None
+
+    @property
+    def ntotal(self) -> int:
+        return 0 if self._c is None else int(self._c.shape[0])
+
+    def reset(self) -> None:
+        self._c = None
+
+    def add(self, c) -> None:
+        c = self.backend._f32(c)
+        assert c.dim() == 2 and c.shape[1] == self.d, f"expected [n, {self.d}]"
+        self._c = c.clone() if self._c is None else torch.cat([self._c, c], 0)
+
+    def search(self, x, k=1):
+        if k != 1:
+            raise NotImplementedError("IndexFlatL2.search: only k=1 is implemented (the reference's use)")
+        host = _is_host(x)
+        be = self.backend
+        x = be._f32(x)
+        assert x.dim() == 2 and x.shape[1] == self.d, f"expected [n, {self.d}]"
+        if self._c is None:
+            D = torch.full((x.shape[0], 1), float("inf"), device=be.device)
+            I = torch.full((x.shape[0], 1), -1, dtype=torch.int64, device=be.device)
+        else:
+            ids, dis = be.assign(x, self._c)
+            D, I = dis.unsqueeze(1), ids.unsqueeze(1)
+        return (be.to_host(D), be.to_host(I)) if host else (D, I)

@@ -1,0 +1,135 @@
+/*
+ * audio_tokens_amd.h -- C ABI of the MI355X (gfx950) audio-tokenisation hot path.
+ *
+ * The reference (danavery/audio-tokens) has no FFI of its own: its three stage classes call two
+ * third-party operators directly.  The entry points below are what a native replacement of those
+ * operators binds; each cites the reference call site it stands in for (paths relative to the
+ * reference repository).
+ *
+ *   torchaudio.transforms.MelSpectrogram(...)(wave) -> AmplitudeToDB()      at_logmel_f32
+ *       processors/spectrogram_generator.py:28-34, 123-126
+ *   np.linalg.norm(axis=1) row normalisation                               at_l2norm_rows_f32
+ *       processors/cluster_creator.py:64-66, processors/spec_tokenizer.py:106-109
+ *   faiss.IndexFlatL2(d).add(c); .search(x, 1)                             at_assign_f32
+ *       processors/spec_tokenizer.py:77, 123-127 (and inside faiss.Kmeans.train)
+ *   faiss.Kmeans(d, k, niter).train(x, init_centroids)                     at_rand_perm_mt19937,
+ *       processors/cluster_creator.py:42-56                                at_gather_rows_f32,
+ *                                                                          at_assign_f32,
+ *                                                                          at_centroid_accum_f32,
+ *                                                                          at_centroid_finalize_f32,
+ *                                                                          at_split_clusters_host,
+ *                                                                          at_sum_f32
+ *
+ * Conventions
+ *   - plain C: raw pointers and sizes, no C++/torch types.  Every `const float*`/`float*` named
+ *     x, c, wave, out, sums ... is a DEVICE pointer on the context's GPU unless the function name
+ *     ends in _host or the parameter says (host).  `stream` is a hipStream_t passed as void*
+ *     (NULL = the default stream).  All device work is enqueued on that stream and is not
+ *     synchronised unless stated.
+ *   - the caller owns every buffer it passes; the library owns only the workspace behind
+ *     at_ctx (grown on demand, freed by at_destroy).  A context is bound to one device and is
+ *     not re-entrant: use one per host thread / stream.
+ *   - return value: 0 = ok, negative = error (AT_E_*); at_last_error() gives the message of the
+ *     calling thread's last failure.  Nothing throws across this boundary.
+ */
+#ifndef AUDIO_TOKENS_AMD_H
+#define AUDIO_TOKENS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AT_VERSION 100 /* 0.1.0 */
+
+#define AT_OK 0
+#define AT_E_INVALID (-1)  /* bad argument (null pointer, size, unsupported shape) */
+#define AT_E_HIP (-2)      /* a HIP runtime call failed */
+#define AT_E_NOMEM (-3)    /* workspace allocation failed */
+#define AT_E_TOO_FEW (-4)  /* faiss: "Number of training points should be at least ..." */
+#define AT_E_NONFINITE (-5)/* faiss: "input contains NaN's or Inf's" */
+
+/* at_logmel_f32 output layouts */
+#define AT_LAYOUT_MEL_MAJOR 0   /* out[clip][n_mels][T]  -- the reference's .npy file layout */
+#define AT_LAYOUT_FRAME_MAJOR 1 /* out[clip*T + t][n_mels] -- what ClusterCreator/SpecTokenizer
+                                   build with np.load(f).T + np.concatenate */
+
+typedef struct at_ctx at_ctx;
+
+/* ---- context -------------------------------------------------------------------------------- */
+int at_version(void);
+const char* at_last_error(void);
+int at_create(int device, at_ctx** out);
+void at_destroy(at_ctx* ctx);
+/* bytes of device workspace currently held by the context */
+int64_t at_workspace_bytes(const at_ctx* ctx);
+
+/* ---- host helpers (no GPU work) --------------------------------------------------------------*/
+/* faiss utils/random.cpp rand_perm(perm, n, seed): std::mt19937 Fisher-Yates. perm: host [n]. */
+int at_rand_perm_mt19937(int64_t n, int64_t seed, int32_t* perm_host);
+/* The first m entries of that same permutation (m <= n) without running the remaining n-m
+ * Fisher-Yates steps, which cannot touch them.  prefix_host: host [m]. */
+int at_rand_perm_prefix_mt19937(int64_t n, int64_t seed, int64_t m, int32_t* prefix_host);
+/* torchaudio.functional.melscale_fbanks(n_fft/2+1, 0, sr//2, n_mels, sr, norm=None, "htk").
+ * fb_host: [n_fft/2+1][n_mels]. */
+int at_mel_filterbank_host(int sample_rate, int n_fft, int n_mels, float* fb_host);
+/* number of STFT frames of an L-sample clip with center=True: 1 + L / hop */
+int64_t at_num_frames(int64_t L, int hop);
+/* faiss Clustering.cpp split_clusters(d, k, n, 0, hassign, centroids) on HOST buffers
+ * (hassign [k], centroids [k][d]); *nsplit receives the number of re-seeded clusters. */
+int at_split_clusters_host(int d, int k, int64_t n, float* hassign_host, float* centroids_host,
+                           int* nsplit);
+
+/* ---- device operators ------------------------------------------------------------------------*/
+/* Fused STFT -> |.|^2 -> mel -> 10*log10(max(.,1e-10)).
+ *   wave: n_clips clips of L samples, clip i at wave + i*wave_stride (floats).
+ *   fb_or_null: DEVICE [n_fft/2+1][n_mels] filterbank, or NULL = the library's own
+ *   (at_mel_filterbank_host values).  n_fft must be 512 in this version; hop divides n_fft.
+ *   out: n_clips*n_mels*T floats in `layout`.  fuse_l2norm != 0 (frame-major only) additionally
+ *   applies at_l2norm_rows_f32 to every frame before it is stored. */
+int at_logmel_f32(at_ctx* ctx, const float* wave, int64_t n_clips, int64_t L, int64_t wave_stride,
+                  int sample_rate, int n_fft, int hop, int n_mels, const float* fb_or_null,
+                  float* out, int layout, int fuse_l2norm, void* stream);
+
+/* y[i] = x[i] / (||x[i]||_2 + 1e-10), fp32, numpy's pairwise summation order (bit-exact with
+ * numpy for finite inputs).  x == y is allowed. */
+int at_l2norm_rows_f32(at_ctx* ctx, const float* x, int64_t n, int d, float* y, void* stream);
+
+/* Nearest centroid under squared L2 (IndexFlatL2.search(x, 1)):
+ *   dis(i,j) = max(0, (|x_i|^2 + |c_j|^2) - 2 <x_i, c_j>), all fp32, inner products and norms as
+ *   ascending-index fmaf chains (v_mfma_f32_32x32x2_f32); ids[i] = lowest j attaining the minimum.
+ *   n < 20 uses faiss's small-batch form sum (x-c)^2 instead (distance_compute_blas_threshold).
+ *   ids: int64 [n]; dist_or_null: float [n]. */
+int at_assign_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
+                  int64_t* ids, float* dist_or_null, void* stream);
+
+/* out[i] = x[idx[i]] (rows of d floats).  idx: DEVICE int32 [m]. */
+int at_gather_rows_f32(at_ctx* ctx, const float* x, int d, const int32_t* idx, int64_t m,
+                       float* out, void* stream);
+
+/* faiss compute_centroids, accumulation half: sums[c] = sum of x[i] with ids[i] == c taken in
+ * ASCENDING i with fp32 adds (bitwise what a single FAISS thread produces), counts[c] = number of
+ * members (exact in fp32).  sums [k][d], counts [k] are overwritten. */
+int at_centroid_accum_f32(at_ctx* ctx, const float* x, int64_t n, int d, const int64_t* ids, int k,
+                          float* sums, float* counts, void* stream);
+
+/* faiss compute_centroids, scaling half, over n_parts partial results (p = data-parallel rank):
+ * part p has its sums [k][d] at sums_parts + p*sums_part_stride and its counts [k] at
+ * counts_parts + p*counts_part_stride (strides in floats).  Partials are added in ascending p,
+ * then centroids[c] = sum * (1/count) where count > 0 and 0 where the cluster is empty;
+ * hassign[c] = count. */
+int at_centroid_finalize_f32(at_ctx* ctx, const float* sums_parts, int64_t sums_part_stride,
+                             const float* counts_parts, int64_t counts_part_stride, int n_parts,
+                             int k, int d, float* centroids, float* hassign, void* stream);
+
+/* *out (DEVICE double) = sum of v[0..n) accumulated in double with a fixed reduction tree. */
+int at_sum_f32(at_ctx* ctx, const float* v, int64_t n, double* out, void* stream);
+
+/* 1 if any of v[0..n) is NaN/Inf else 0, written to *flag (DEVICE int32). */
+int at_any_nonfinite_f32(at_ctx* ctx, const float* v, int64_t n, int32_t* flag, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUDIO_TOKENS_AMD_H */

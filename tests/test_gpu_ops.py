@@ -1,0 +1,168 @@
+"""GPU parity: every device operator of the C ABI against the CPU oracle on the same inputs.
+
+Bar: bit-exact for ids / distances / centroid sums / row normalisation (integer-like and
+order-pinned fp32 work); log-mel within the tolerance stated in test_logmel (fp32 FFT vs the
+oracle's exact value)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _unit_rows(rng, n, d, oracle):
+    return oracle.l2norm_rows(rng.standard_normal((n, d)).astype(np.float32))
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("n,d,k", [(1000, 64, 256), (4099, 64, 500), (513, 128, 100), (2048, 128, 8192),
+                                   (100000, 64, 8192), (3000, 64, 64), (777, 64, 1)])
+def test_assign_bit_exact(be, oracle, n, d, k):
+    rng = np.random.default_rng(n * 7 + k)
+    x = _unit_rows(rng, n, d, oracle)
+    c = _unit_rows(rng, k, d, oracle)
+    ids_o, dis_o = oracle.assign(x, c)
+    ids, dis = be.assign(x, c)
+    ids, dis = ids.cpu().numpy(), dis.cpu().numpy()
+    assert np.array_equal(ids, ids_o), f"{(ids != ids_o).sum()} of {n} ids differ"
+    assert np.array_equal(bits(dis), bits(dis_o))
+
+
+def test_assign_unnormalised_and_ties(be, oracle):
+    rng = np.random.default_rng(5)
+    # un-normalised rows, duplicated centroids (exact ties -> lowest index), duplicated rows
+    x = (rng.standard_normal((5000, 64)) * rng.uniform(0.1, 30, (5000, 1))).astype(np.float32)
+    c = (rng.standard_normal((300, 64)) * 5).astype(np.float32)
+    c[200:250] = c[0:50]          # exact duplicates of lower-index centroids
+    x[100:150] = c[200:250]       # rows identical to a duplicated centroid: dis clamps to 0 on both
+    ids_o, dis_o = oracle.assign(x, c)
+    ids, dis = be.assign(x, c)
+    assert np.array_equal(ids.cpu().numpy(), ids_o)
+    assert np.array_equal(bits(dis.cpu().numpy()), bits(dis_o))
+    assert (ids_o[100:150] < 200).all()
+
+
+@pytest.mark.parametrize("n", [1, 5, 19])
+def test_assign_small_batch_form(be, oracle, n):
+    rng = np.random.default_rng(n)
+    x = _unit_rows(rng, n, 64, oracle)
+    c = _unit_rows(rng, 300, 64, oracle)
+    ids_o, dis_o = oracle.assign(x, c)
+    ids, dis = be.assign(x, c)
+    assert np.array_equal(ids.cpu().numpy(), ids_o)
+    assert np.array_equal(bits(dis.cpu().numpy()), bits(dis_o))
+
+
+@pytest.mark.parametrize("d,k", [(8, 20), (40, 33), (80, 500), (640, 64)])
+def test_assign_generic_d(be, oracle, d, k):
+    rng = np.random.default_rng(d + k)
+    x = _unit_rows(rng, 1500, d, oracle)
+    c = _unit_rows(rng, k, d, oracle)
+    ids_o, dis_o = oracle.assign(x, c)
+    ids, dis = be.assign(x, c)
+    assert np.array_equal(ids.cpu().numpy(), ids_o)
+    assert np.array_equal(bits(dis.cpu().numpy()), bits(dis_o))
+
+
+@pytest.mark.parametrize("n,d", [(1, 64), (1000, 64), (777, 128), (300, 3), (100, 130), (64, 640), (5000, 20)])
+def test_l2norm_rows_bit_exact_vs_numpy(be, n, d):
+    rng = np.random.default_rng(n + d)
+    x = (rng.standard_normal((n, d)) * rng.uniform(1e-3, 1e2, (n, 1))).astype(np.float32)
+    if n > 3:
+        x[3] = 0.0  # silent frame: 0 / 1e-10 = 0
+    ref = x / (np.linalg.norm(x, axis=1, keepdims=True) + 1e-10)
+    got = be.l2norm_rows(x).cpu().numpy()
+    assert ref.dtype == np.float32
+    assert np.array_equal(bits(got), bits(ref))
+
+
+def test_gather_rows(be):
+    rng = np.random.default_rng(0)
+    for d in (64, 128, 7):
+        x = rng.standard_normal((1000, d)).astype(np.float32)
+        idx = rng.integers(0, 1000, 333).astype(np.int32)
+        got = be.gather_rows(x, idx).cpu().numpy()
+        assert np.array_equal(got, x[idx])
+
+
+@pytest.mark.parametrize("n,d,k", [(5000, 64, 37), (20000, 64, 500), (3000, 128, 64), (2000, 640, 10), (1000, 8, 5)])
+def test_centroid_accum_is_the_sequential_sum(be, n, d, k):
+    rng = np.random.default_rng(n + d + k)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    ids = rng.integers(0, k, n).astype(np.int64)
+    ids[ids == 3] = 4  # cluster 3 empty
+    # skewed: one heavy cluster
+    ids[: n // 3] = 1
+    sums = np.zeros((k, d), np.float32)
+    counts = np.zeros(k, np.float32)
+    for i in range(n):  # ascending i, fp32 adds: what FAISS' owning thread does
+        sums[ids[i]] += x[i]
+        counts[ids[i]] += 1
+    part = be.centroid_accum(be._f32(x), torch.from_numpy(ids).to(be.device), k).cpu().numpy()
+    assert np.array_equal(bits(part[: k * d].reshape(k, d)), bits(sums))
+    assert np.array_equal(part[k * d:], counts)
+    cent, h = be.centroid_finalize(torch.from_numpy(part).to(be.device), k, d)
+    ref = sums.copy()
+    nz = counts > 0
+    ref[nz] = sums[nz] * (np.float32(1.0) / counts[nz])[:, None]
+    assert np.array_equal(bits(cent.cpu().numpy()), bits(ref))
+    assert np.array_equal(h.cpu().numpy(), counts)
+
+
+def test_sum_and_nonfinite(be):
+    rng = np.random.default_rng(1)
+    v = rng.random(1_000_003).astype(np.float32)
+    s = be.sum_f64(v).item()
+    assert abs(s - v.astype(np.float64).sum()) <= 1e-9 * s
+    assert not be.any_nonfinite(v)
+    v[12345] = np.inf
+    assert be.any_nonfinite(v)
+    v[12345] = np.nan
+    assert be.any_nonfinite(v)
+
+
+def _logmel_tolerance(got, ref):
+    """fp32 FFT noise floor: |dP| <= 2e-5*P + 1e-9*max_frame(P) in the power domain (a frame's
+    bins far below its peak are rounding noise in torchaudio's fp32 pipeline too)."""
+    P, Pr = 10.0 ** (got.astype(np.float64) / 10), 10.0 ** (ref.astype(np.float64) / 10)
+    pmax = Pr.max(axis=-2, keepdims=True)
+    return np.abs(P - Pr) <= 2e-5 * Pr + 1e-9 * pmax + 1e-10 * 1e-4
+
+
+@pytest.mark.parametrize("n_mels", [64, 128])
+def test_logmel_vs_oracle(be, oracle, n_mels):
+    rng = np.random.default_rng(3)
+    L = 22050
+    t = np.arange(L) / 22050.0
+    clips = np.stack([
+        0.4 * np.sin(2 * np.pi * 440 * t),
+        0.3 * np.sin(2 * np.pi * (100 * t + 4000 * t * t)),
+        0.05 * rng.standard_normal(L),
+        0.3 * np.sin(2 * np.pi * 1000 * t) + 1e-3 * rng.standard_normal(L),
+        np.where(np.arange(L) == 9000, 0.9, 0.0),
+        np.zeros(L),
+    ]).astype(np.float32)
+    ref = np.stack([oracle.logmel(c, n_mels=n_mels) for c in clips])
+    got = be.logmel(clips, n_mels=n_mels).cpu().numpy()
+    assert got.shape == ref.shape == (6, n_mels, 173)
+    ok = _logmel_tolerance(got, ref)
+    assert ok.all(), f"{(~ok).sum()} of {ok.size} bins outside tolerance; worst dB diff {np.abs(got - ref)[~ok].max()}"
+    assert (got[5] == -100.0).all()                       # digital silence -> exactly -100 dB
+    # frame-major layout and the fused row normalisation
+    fm = be.logmel(clips, n_mels=n_mels, frame_major=True).cpu().numpy()
+    assert np.array_equal(fm.reshape(6, 173, n_mels), got.transpose(0, 2, 1))
+    fmn = be.logmel(clips, n_mels=n_mels, frame_major=True, l2norm=True).cpu().numpy()
+    ref_n = fm / (np.linalg.norm(fm, axis=1, keepdims=True) + 1e-10)
+    assert np.array_equal(bits(fmn), bits(ref_n))
+
+
+def test_logmel_full_length_clip_shapes(be, oracle):
+    rng = np.random.default_rng(4)
+    w = (0.1 * rng.standard_normal((3, 220500))).astype(np.float32)
+    got = be.logmel(w).cpu().numpy()
+    assert got.shape == (3, 64, 1723)
+    ref = oracle.logmel(w[1])
+    assert _logmel_tolerance(got[1], ref).all()
