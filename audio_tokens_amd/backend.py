@@ -76,6 +76,7 @@ class HipBackend(HostHelpers):
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = device
         self.ctx = _lib.context(device.index)
+        self.assign_trace = None  # set to a list to collect (n, d, k, start_event, end_event)
 
     # -- plumbing --------------------------------------------------------------------------
     def _stream(self) -> _vp:
@@ -156,9 +157,16 @@ class HipBackend(HostHelpers):
         k = c.shape[0]
         ids = self.empty((n,), torch.int64)
         dist = self.empty((n,), torch.float32) if want_dist else None
+        rec = self.assign_trace
+        if rec is not None:  # bench.py: HIP events on the launch stream around every assign launch
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.device))
         with torch.cuda.device(self.device):
             _lib.check(self.lib.at_assign_f32(self.ctx.handle, _ptr(x), n, d, _ptr(c), k, _ptr(ids),
                                               _ptr(dist), self._stream()))
+        if rec is not None:
+            e1.record(torch.cuda.current_stream(self.device))
+            rec.append((n, d, k, e0, e1))
         return ids, dist
 
     def gather_rows(self, x, idx) -> torch.Tensor:

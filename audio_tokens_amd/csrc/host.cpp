@@ -171,14 +171,22 @@ int at_split_clusters_host(int d, int k, int64_t n, float* hassign, float* centr
     FaissRng rng(1234);
     int count = 0;
     const float denom = (float)(n - k);
+    // acceptance probability (size-1)/(n-k) of every cluster, kept up to date as sizes change;
+    // one draw is consumed per candidate visited, exactly as in FAISS, so this loop is the
+    // sequential heart of the repair and is kept as tight as possible
+    auto prob = [&](int c) { return (float)((hassign[c] - 1.0) / denom); };
+    std::vector<float> p((size_t)k);
+    bool have_p = false;
     for (int ci = 0; ci < k; ci++) {
         if (hassign[ci] != 0.0f) continue;
-        // walk the clusters cyclically until one accepts with probability (size-1)/(n-k)
+        if (!have_p) {
+            for (int c = 0; c < k; c++) p[c] = prob(c);
+            have_p = true;
+        }
+        // walk the clusters cyclically from 0 until one accepts
         int donor = 0;
-        while (true) {
-            const float p = (float)((hassign[donor] - 1.0) / denom);
-            if (rng.rand_float() < p) break;
-            donor = (donor + 1) % k;
+        while (!(rng.rand_float() < p[donor])) {
+            if (++donor == k) donor = 0;
         }
         float* dst = centroids + (size_t)ci * d;
         float* src = centroids + (size_t)donor * d;
@@ -195,6 +203,8 @@ int at_split_clusters_host(int d, int k, int64_t n, float* hassign, float* centr
         }
         hassign[ci] = hassign[donor] / 2;
         hassign[donor] -= hassign[ci];
+        p[ci] = prob(ci);
+        p[donor] = prob(donor);
         count++;
     }
     if (nsplit) *nsplit = count;

@@ -77,7 +77,7 @@ template <int VEC>
 __global__ void __launch_bounds__(WG) centroid_accum_kernel(const float* __restrict__ x, int d,
                                                             const uint32_t* __restrict__ order,
                                                             const uint32_t* __restrict__ offsets,
-                                                            int k, int slabs,
+                                                            int k, int slabs, uint32_t long_list,
                                                             float* __restrict__ sums,
                                                             float* __restrict__ counts) {
     const int lane = threadIdx.x & 63;
@@ -88,6 +88,7 @@ __global__ void __launch_bounds__(WG) centroid_accum_kernel(const float* __restr
     const int f0 = (slab * 64 + lane) * VEC;
     const bool live = f0 < d;  // d is a multiple of VEC
     const uint32_t beg = offsets[c], end = offsets[c + 1];
+    if (end - beg > long_list) return;  // left to centroid_accum_long_kernel
 
     float acc[VEC];
 #pragma unroll
@@ -128,6 +129,83 @@ __global__ void __launch_bounds__(WG) centroid_accum_kernel(const float* __restr
         for (int v = 0; v < VEC; v++) sums[(size_t)c * d + f0 + v] = acc[v];
     }
     if (slab == 0 && lane == 0) counts[c] = (float)(end - beg);
+}
+
+// Long member lists (one huge cluster, e.g. every digital-silence frame) would leave a single
+// wavefront chasing HBM latency for milliseconds.  The sums of different features are independent,
+// so such a cluster is cut ACROSS FEATURES: one workgroup per (long cluster, 4-feature slice).
+// Waves 1-3 stream that 16-byte slice of every member row, in member order, into a
+// double-buffered LDS ring (all index loads, then all row loads, then the LDS writes, so a whole
+// chunk is in flight at once); four lanes of wave 0 do nothing but the dependent chain of fp32
+// adds.  Same ascending-member order, hence the same bits, as the one-wave kernel.
+constexpr int LONG_CHUNK = 2048;                       // members per ring buffer (32 KiB)
+constexpr int LONG_LOADERS = WG - 64;                  // threads that load
+constexpr int LONG_PER_THREAD = (LONG_CHUNK + LONG_LOADERS - 1) / LONG_LOADERS;
+
+__global__ void __launch_bounds__(WG) centroid_accum_long_kernel(const float* __restrict__ x, int d,
+                                                                 const uint32_t* __restrict__ order,
+                                                                 const uint32_t* __restrict__ offsets,
+                                                                 uint32_t long_list,
+                                                                 float* __restrict__ sums,
+                                                                 float* __restrict__ counts) {
+    __shared__ __attribute__((aligned(16))) float4 ring[2][LONG_CHUNK];
+    const int c = blockIdx.x;
+    const int piece = blockIdx.y;  // features 4*piece .. 4*piece+3
+    const uint32_t beg = offsets[c], end = offsets[c + 1];
+    const uint32_t len = end - beg;
+    if (len <= long_list) return;  // uniform for the workgroup
+    const int tid = threadIdx.x;
+    const bool adder = tid < 64;
+    const uint32_t nchunks = (len + LONG_CHUNK - 1) / LONG_CHUNK;
+    const float4* rows = reinterpret_cast<const float4*>(x) + piece;
+    const int d4 = d >> 2;
+
+    auto stage = [&](uint32_t ch) {  // loaders only
+        const uint32_t m0 = ch * LONG_CHUNK;
+        const uint32_t cnt = min((uint32_t)LONG_CHUNK, len - m0);
+        const uint32_t t = tid - 64;
+        uint32_t src[LONG_PER_THREAD];
+        float4 v[LONG_PER_THREAD];
+#pragma unroll
+        for (int u = 0; u < LONG_PER_THREAD; u++) {
+            const uint32_t e = t + u * LONG_LOADERS;
+            src[u] = e < cnt ? order[beg + m0 + e] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < LONG_PER_THREAD; u++) {
+            const uint32_t e = t + u * LONG_LOADERS;
+            v[u] = e < cnt ? rows[(size_t)src[u] * d4] : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < LONG_PER_THREAD; u++) {
+            const uint32_t e = t + u * LONG_LOADERS;
+            if (e < cnt) ring[ch & 1][e] = v[u];
+        }
+    };
+
+    float acc = 0.0f;
+    if (!adder) stage(0);
+    __syncthreads();
+    for (uint32_t ch = 0; ch < nchunks; ch++) {
+        if (!adder) {
+            if (ch + 1 < nchunks) stage(ch + 1);
+        } else if (tid < 4) {
+            const float* src = reinterpret_cast<const float*>(ring[ch & 1]) + tid;
+            const uint32_t cnt = min((uint32_t)LONG_CHUNK, len - ch * LONG_CHUNK);
+            uint32_t m = 0;
+            for (; m + 16 <= cnt; m += 16) {
+                float t[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) t[u] = src[4 * (m + u)];
+#pragma unroll
+                for (int u = 0; u < 16; u++) acc += t[u];
+            }
+            for (; m < cnt; m++) acc += src[4 * m];
+        }
+        __syncthreads();
+    }
+    if (tid < 4) sums[(size_t)c * d + 4 * piece + tid] = acc;
+    if (tid == 0 && piece == 0) counts[c] = (float)len;
 }
 
 __global__ void __launch_bounds__(WG) centroid_finalize_kernel(const float* __restrict__ sums_parts,
@@ -266,15 +344,24 @@ int at_centroid_accum_f32(at_ctx* ctx, const float* x, int64_t n, int d, const i
     const int slabs = (d + 64 * vec - 1) / (64 * vec);
     const long waves = (long)k * slabs;
     const dim3 grid((unsigned)((waves + WG / 64 - 1) / (WG / 64)));
+    // member lists longer than this go to the feature-sliced workgroup kernel
+    const bool long_ok = d % 4 == 0 && al;
+    const uint32_t long_list = long_ok ? 2048u : UINT32_MAX;
     if (vec == 4)
         hipLaunchKernelGGL(centroid_accum_kernel<4>, grid, dim3(WG), 0, stream, x, d, order, offsets, k,
-                           slabs, sums, counts);
+                           slabs, long_list, sums, counts);
     else if (vec == 2)
         hipLaunchKernelGGL(centroid_accum_kernel<2>, grid, dim3(WG), 0, stream, x, d, order, offsets, k,
-                           slabs, sums, counts);
+                           slabs, long_list, sums, counts);
     else
         hipLaunchKernelGGL(centroid_accum_kernel<1>, grid, dim3(WG), 0, stream, x, d, order, offsets, k,
-                           slabs, sums, counts);
+                           slabs, long_list, sums, counts);
+    AT_LAUNCH_CHECK();
+    if (long_ok && n > (int64_t)long_list) {
+        // (workgroups of short clusters exit at once; gridDim.y = feature slices)
+        hipLaunchKernelGGL(centroid_accum_long_kernel, dim3(k, d / 4), dim3(WG), 0, stream, x, d, order,
+                           offsets, long_list, sums, counts);
+    }
     AT_LAUNCH_CHECK();
     return AT_OK;
 }

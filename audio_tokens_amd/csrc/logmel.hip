@@ -92,8 +92,9 @@ __global__ void __launch_bounds__(WG, 2) logmel_kernel(LogmelParams p) {
             const int m = l16 + 16 * i;
             if (m < p.n_mels) {
                 float s = mel_band(mybuf, p.fb_start[m], p.fb_len[m], p.fb_wts + p.fb_off[m]);
-                s = fmaxf(s, 1e-10f);
-                ostage[f * opitch + m] = 10.0f * log10f(s);
+                // clamp(x, 1e-10) then 10*log10: a clamped bin is exactly -100 dB (what a correctly
+                // rounded log10 of 1e-10f gives; the device log10f is 1 ulp off there)
+                ostage[f * opitch + m] = s > 1e-10f ? 10.0f * log10f(s) : -100.0f;
             }
         }
     }

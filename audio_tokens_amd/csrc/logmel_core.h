@@ -32,7 +32,11 @@ struct cpx {
 
 AT_HD cpx cadd(cpx a, cpx b) { return {a.re + b.re, a.im + b.im}; }
 AT_HD cpx csub(cpx a, cpx b) { return {a.re - b.re, a.im - b.im}; }
-AT_HD cpx cmul(cpx a, cpx w) { return {a.re * w.re - a.im * w.im, a.re * w.im + a.im * w.re}; }
+// Fused multiply-adds are written out (the library is compiled with -ffp-contract=off so that
+// the bit-exact kernels elsewhere are not at the optimiser's mercy).
+AT_HD cpx cmul(cpx a, cpx w) {
+    return {__builtin_fmaf(a.re, w.re, -(a.im * w.im)), __builtin_fmaf(a.re, w.im, a.im * w.re)};
+}
 
 // forward DFT of 4 points, outputs in natural order
 AT_HD void dft4(cpx& a, cpx& b, cpx& c, cpx& d) {
@@ -82,7 +86,7 @@ AT_HD void phase1(int l, const float* frame, const float* win, const float* tw25
 #pragma unroll
     for (int m1 = 0; m1 < 16; m1++) {
         const int s = 32 * m1 + 2 * l;
-        v[m1] = {frame[s] * win[s], frame[s + 1] * win[s + 1]};
+        v[m1] = {frame[s] * win[s], frame[s + 1] * win[s + 1]};  // torch: frames * window, fp32
     }
     dft16(v);  // v[k1]
 #pragma unroll
@@ -127,7 +131,7 @@ AT_HD void phase3_power(int l, const cpx (&z)[16], const float* zbuf, const floa
         const cpx od = {df.im, -df.re};               // -i * df
         const cpx w = {tw512[2 * k], tw512[2 * k + 1]};
         const cpx x = cadd(ev, cmul(od, w));
-        p[e] = x.re * x.re + x.im * x.im;
+        p[e] = __builtin_fmaf(x.re, x.re, x.im * x.im);
         if (k == 0) {
             const float n = a.re - a.im;              // X[256] = Re Z0 - Im Z0 (purely real)
             p256 = n * n;
@@ -138,7 +142,7 @@ AT_HD void phase3_power(int l, const cpx (&z)[16], const float* zbuf, const floa
 // Phase 4: one mel filter = banded dot product over the power spectrum, then dB.
 AT_HD float mel_band(const float* pw, int start, int len, const float* wts) {
     float s = 0.0f;
-    for (int w = 0; w < len; w++) s += pw[start + w] * wts[w];
+    for (int w = 0; w < len; w++) s = __builtin_fmaf(pw[start + w], wts[w], s);
     return s;
 }
 

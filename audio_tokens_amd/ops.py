@@ -166,6 +166,7 @@ class Kmeans:
         self.obj = np.zeros(0, np.float32)
         self.iteration_stats = []
         self.index = None
+        self.phase_seconds = None
 
     # ------------------------------------------------------------------------------------
     def train(self, x, init_centroids=None):
@@ -237,16 +238,30 @@ class Kmeans:
         obj_host = be.host_staging((1,), torch.float64)
         t0 = time.time()
         t_search = 0.0
+        prof = self.phase_seconds  # None, or a dict that collects per-phase wall time (debug aid)
+
+        def lap(name, t_prev):
+            if prof is None:
+                return t_prev
+            be.synchronize()
+            now = time.perf_counter()
+            prof[name] = prof.get(name, 0.0) + (now - t_prev)
+            return now
+
         for it in range(self.niter):
             ts = time.time()
+            tp = time.perf_counter()
             ids, dis = be.assign(xs, cent)
+            tp = lap("assign", tp)
             obj = dist.sum_f64(be.sum_f64(dis))
             part = be.centroid_accum(xs, ids, k)
+            tp = lap("accumulate", tp)
             parts = dist.all_gather_parts(part)
             cent, hassign = be.centroid_finalize(parts, k, d)
             hassign_host.copy_(hassign, non_blocking=True)
             obj_host.copy_(obj, non_blocking=True)
             be.synchronize()
+            tp = lap("exchange+finalize+readback", tp)
             t_search += time.time() - ts  # (the whole iteration is device work here)
             h = hassign_host.numpy()
             hd = h.astype(np.float64)
@@ -257,6 +272,7 @@ class Kmeans:
                 h_work = h.copy()
                 nsplit = be.split_clusters(h_work, c_host, ns)
                 cent = be.from_host(c_host)
+            tp = lap("split", tp)
             st = dict(obj=float(np.float32(obj_host.item())), time=time.time() - t0, time_search=t_search,
                       imbalance_factor=imbalance, nsplit=nsplit)
             self.iteration_stats.append(st)

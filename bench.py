@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- STFT frames/sec through log-mel -> K-means -> tokenise on MI355X.
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): STFT frames/sec through K-means+tokenize, n_mels=64, vocab=8192.
+Workload: configs[3] ("unbal_train 200k-clip subset, n_mels=64, vocab_size=8192, 8 GPUs") cut into
+its eight per-GPU shards -- 22 500 train + 2 500 validation synthetic 10 s clips per GPU (weak
+scaling: N GPUs process N shards; N = 8 is configs[3] itself).  One step = one full pass of the hot
+path over the resident waveforms: fused log-mel (frame-major, unit rows) -> one FAISS-style
+Kmeans.train per batch of 10 000 files (20 Lloyd iterations on a 2 097 152-row subsample, warm
+started) -> centroid normalisation -> nearest-centroid tokens for every frame.  Inputs are in HBM
+before the timed region starts.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def cpu_baseline(n_mels, vocab, L, hop, seed, clips, niter):
+    """The oracle (CPU restatement, kind="port") timed on this box's host cores on a bounded
+    sample of the same workload.  Only this function touches oracle/."""
+    import oracle
+    from audio_tokens_amd.synth import synth_clips
+    oracle.build()
+    wave = synth_clips(clips, L=L, seed=seed, first_clip=0, device="cpu").numpy()
+    t0 = time.perf_counter()
+    specs = [oracle.logmel(w, n_mels=n_mels, hop=hop) for w in wave]
+    x = np.concatenate([s.T for s in specs], axis=0).astype(np.float32)
+    x = oracle.l2norm_rows(x)
+    t1 = time.perf_counter()
+    r = oracle.kmeans_train(x, vocab, niter=niter)
+    c = oracle.l2norm_rows(r.centroids)
+    t2 = time.perf_counter()
+    oracle.assign(x, c)
+    t3 = time.perf_counter()
+    frames = x.shape[0]
+    return {
+        "value": frames / (t3 - t0),
+        "unit": "frames/s",
+        "cores": oracle.num_threads(),
+        "kind": "port",
+        "sample": (f"{clips} clips ({frames} frames) of the same synthetic stream: log-mel, one Kmeans.train "
+                   f"(k={vocab}, niter={niter} ~ the full job's 2.9 Lloyd point-iterations per frame), tokenise; "
+                   f"seconds: logmel {t1 - t0:.2f}, kmeans {t2 - t1:.2f}, tokenise {t3 - t2:.2f}; "
+                   f"host has {os.cpu_count()} logical cores"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--train-clips", type=int, default=22500, help="per GPU")
+    ap.add_argument("--val-clips", type=int, default=2500, help="per GPU")
+    ap.add_argument("--n-mels", type=int, default=64)
+    ap.add_argument("--vocab", type=int, default=8192)
+    ap.add_argument("--niter", type=int, default=20)
+    ap.add_argument("--clip-seconds", type=float, default=10.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-clips", type=int, default=256)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from audio_tokens_amd.backend import default_backend
+    from audio_tokens_amd.pipeline import DevicePipeline
+    from audio_tokens_amd.synth import synth_clips
+
+    be = default_backend(device)
+    sr, hop, n_fft = 22050, 128, 512
+    L = int(round(args.clip_seconds * sr))
+    T = be.num_frames(L, hop)
+    seed = 4242
+    n_tr, n_va = args.train_clips, args.val_clips
+    # global clip ids: train clips first (rank-major inside every 10 000-file batch is implied by
+    # the sharded Kmeans), then validation clips; any rank can generate its own shard
+    wave_tr = synth_clips(n_tr, L=L, seed=seed, first_clip=rank * n_tr, device=device)
+    wave_va = synth_clips(n_va, L=L, seed=seed, first_clip=world * n_tr + rank * n_va, device=device)
+
+    pipe = DevicePipeline(n_mels=args.n_mels, vocab_size=args.vocab, niter=args.niter, sample_rate=sr,
+                          n_fft=n_fft, hop_length=hop, clustering_batch_size=10000,
+                          distributed=world > 1, backend=be)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        res = pipe.run(wave_tr, wave_va)
+    be.assign_trace = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = pipe.run(wave_tr, wave_va)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    trace, be.assign_trace = be.assign_trace, None
+    stage = pipe.run(wave_tr, wave_va, timing=True).stage_seconds  # one extra, untimed, per-stage split
+
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    frames_per_step = (n_tr + n_va) * T * world
+    value = frames_per_step * args.steps / elapsed
+
+    # roofline of the dominant kernel (assign_mfma_kernel: -2XC^T on fp32 MFMA + arg-min), from HIP
+    # events recorded on the launch stream around every at_assign_f32 launch of the timed steps
+    flops = sum(2.0 * n * d * k for (n, d, k, _, _) in trace)
+    ms = sum(e0.elapsed_time(e1) for (_, _, _, e0, e1) in trace)
+    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    traffic = None
+    tfile = ROOT / "profiles" / "assign_traffic.json"
+    if tfile.exists():
+        try:
+            traffic = json.loads(tfile.read_text()).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {
+        "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+        "kernel": "assign_mfma_kernel<64,2> (at_assign_f32)", "launches": len(trace),
+        "avg_launch_ms": ms / max(1, len(trace)), "flop_per_launch": flops / max(1, len(trace)),
+        "share_of_step_time": (ms * 1e-3) / elapsed if elapsed > 0 else None,
+    }
+
+    out = {
+        "metric": "STFT frames/sec through K-means+tokenize, n_mels=64 vocab=8192",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": (f"configs[3] per-GPU shard x{world}: {n_tr}+{n_va} clips/GPU of {args.clip_seconds:g} s @22.05 kHz "
+                         f"({(n_tr + n_va) * T} frames/GPU), n_mels={args.n_mels}, vocab_size={args.vocab}, niter={args.niter}, "
+                         f"k-means batches of 10000 files on a {min(256 * args.vocab, 10000 * T)}-row subsample"),
+            "frames_per_step": frames_per_step, "parallelism": f"dp{world}",
+        },
+        "stage_seconds": stage,
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.n_mels, args.vocab, L, hop, seed, args.cpu_clips, niter=3)
+    else:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,7 +1,7 @@
 """Ad-hoc timing of single operators on the GPU box (development aid, not the contract bench)."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from audio_tokens_amd.backend import default_backend
 
 be = default_backend()
