@@ -100,9 +100,9 @@ class _Dist:
         """part [m] float32 -> [world, m], rank order."""
         if not self.on:
             return part.unsqueeze(0)
-        out = torch.empty((self.world, part.numel()), dtype=part.dtype, device=part.device)
-        self.dist.all_gather_into_tensor(out, part, group=self.group)
-        return out
+        out = torch.empty(self.world * part.numel(), dtype=part.dtype, device=part.device)
+        self.dist.all_gather_into_tensor(out, part.reshape(-1), group=self.group)
+        return out.view(self.world, part.numel())
 
     def sum_bits(self, rows):
         """Exact merge of float32 rows of which exactly one rank holds a non-zero copy."""

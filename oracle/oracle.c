@@ -175,7 +175,8 @@ int orc_mel_filterbank(int sample_rate, int n_fft, int n_mels, float* fb) {
 
 int64_t orc_num_frames(int64_t L, int hop) { return 1 + L / hop; }
 
-static void fft_radix2(double* re, double* im, int n) {
+/* in-place radix-2 FFT; tw[2j], tw[2j+1] = cos, -sin of 2*pi*j/n for j < n/2 */
+static void fft_radix2(double* re, double* im, int n, const double* tw) {
     for (int i = 1, j = 0; i < n; i++) {
         int bit = n >> 1;
         for (; j & bit; bit >>= 1) j ^= bit;
@@ -186,10 +187,10 @@ static void fft_radix2(double* re, double* im, int n) {
         }
     }
     for (int len = 2; len <= n; len <<= 1) {
-        double ang = -2.0 * M_PI / (double)len;
+        int step = n / len;
         for (int i = 0; i < n; i += len) {
             for (int k = 0; k < len / 2; k++) {
-                double wr = cos(ang * k), wi = sin(ang * k);
+                double wr = tw[2 * k * step], wi = tw[2 * k * step + 1];
                 int a = i + k, b = i + k + len / 2;
                 double xr = re[b] * wr - im[b] * wi, xi = re[b] * wi + im[b] * wr;
                 re[b] = re[a] - xr; im[b] = im[a] - xi;
@@ -216,6 +217,11 @@ int orc_logmel(const float* wave, int64_t L, int sample_rate, int n_fft, int hop
     float* win = (float*)malloc(sizeof(float) * (size_t)n_fft);
     for (int i = 0; i < n_fft; i++) /* torch.hann_window(n_fft, periodic=True), fp32 */
         win[i] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * (double)i / (double)n_fft));
+    double* tw = (double*)malloc(sizeof(double) * (size_t)n_fft);
+    for (int j = 0; j < n_fft / 2; j++) {
+        tw[2 * j] = cos(2.0 * M_PI * (double)j / (double)n_fft);
+        tw[2 * j + 1] = -sin(2.0 * M_PI * (double)j / (double)n_fft);
+    }
 #pragma omp parallel
     {
         double* re = (double*)malloc(sizeof(double) * (size_t)n_fft);
@@ -230,11 +236,14 @@ int orc_logmel(const float* wave, int64_t L, int sample_rate, int n_fft, int hop
                 re[i] = (double)wave[p] * (double)win[i];
                 im[i] = 0.0;
             }
-            fft_radix2(re, im, n_fft);
+            fft_radix2(re, im, n_fft, tw);
             for (int f = 0; f < n_freqs; f++) pw[f] = re[f] * re[f] + im[f] * im[f];
             for (int m = 0; m < n_mels; m++) {
                 double s = 0.0;
-                for (int f = 0; f < n_freqs; f++) s += pw[f] * (double)fb[(size_t)f * n_mels + m];
+                for (int f = 0; f < n_freqs; f++) {
+                    const float wgt = fb[(size_t)f * n_mels + m];
+                    if (wgt != 0.0f) s += pw[f] * (double)wgt;
+                }
                 if (s < 1e-10) s = 1e-10;
                 out[(size_t)m * T + t] = (float)(10.0 * log10(s));
             }
@@ -242,6 +251,7 @@ int orc_logmel(const float* wave, int64_t L, int sample_rate, int n_fft, int hop
         free(re); free(im); free(pw);
     }
     free(win);
+    free(tw);
     free(fb_own);
     return 0;
 }

@@ -1,0 +1,80 @@
+"""CPU stand-in for audio_tokens_amd.backend.HipBackend, built on the oracle.  TEST ONLY.
+
+It exists so that the HOST logic of audio_tokens_amd.ops (FAISS training recipe, subsample
+sharding, the per-iteration exchange under torch.distributed) can run in this GPU-less container
+and under gloo with world_size 2.  The product never imports it; the sequential host helpers
+(rand_perm, split_clusters) are the product's own native ones."""
+import numpy as np
+import torch
+
+import oracle
+from audio_tokens_amd.backend import HostHelpers
+
+
+class OracleBackend(HostHelpers):
+    def __init__(self):
+        super().__init__()
+        self.device = torch.device("cpu")
+        self.assign_trace = None
+
+    def _f32(self, t, name="tensor"):
+        if isinstance(t, np.ndarray):
+            t = torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32))
+        return t.float().contiguous()
+
+    def empty(self, shape, dtype=torch.float32):
+        return torch.empty(shape, dtype=dtype)
+
+    def zeros(self, shape, dtype=torch.float32):
+        return torch.zeros(shape, dtype=dtype)
+
+    def from_host(self, a, dtype=None):
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        return t.to(dtype) if dtype is not None else t
+
+    def to_host(self, t):
+        return t.detach().numpy()
+
+    def host_staging(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype)
+
+    def synchronize(self):
+        pass
+
+    def l2norm_rows(self, x, out=None):
+        return torch.from_numpy(oracle.l2norm_rows(self._f32(x).numpy()))
+
+    def assign(self, x, c, want_dist=True):
+        ids, dis = oracle.assign(self._f32(x).numpy(), self._f32(c).numpy())
+        return torch.from_numpy(ids), (torch.from_numpy(dis) if want_dist else None)
+
+    def gather_rows(self, x, idx):
+        idx = idx if isinstance(idx, np.ndarray) else idx.numpy()
+        return self._f32(x)[torch.from_numpy(idx.astype(np.int64))].contiguous()
+
+    def centroid_accum(self, x, ids, k, out=None):
+        x = self._f32(x).numpy()
+        d = x.shape[1]
+        sums = np.zeros((k, d), np.float32)
+        counts = np.zeros(k, np.float32)
+        np.add.at(sums, ids.numpy(), x)          # unbuffered, ascending i: the sequential fp32 sum
+        np.add.at(counts, ids.numpy(), np.float32(1))
+        return torch.from_numpy(np.concatenate([sums.ravel(), counts]))
+
+    def centroid_finalize(self, parts, k, d):
+        parts = parts.reshape(-1, k * d + k).numpy()
+        tot = np.zeros(k * d, np.float32)
+        cnt = np.zeros(k, np.float32)
+        for p in parts:                          # ascending rank order
+            tot = tot + p[: k * d]
+            cnt = cnt + p[k * d:]
+        cent = tot.reshape(k, d).copy()
+        nz = cnt != 0
+        cent[nz] = cent[nz] * (np.float32(1.0) / cnt[nz])[:, None]
+        return torch.from_numpy(cent), torch.from_numpy(cnt)
+
+    def sum_f64(self, v):
+        return torch.tensor([float(self._f32(v).double().sum())], dtype=torch.float64)
+
+    def any_nonfinite(self, v):
+        return not bool(torch.isfinite(self._f32(v)).all())

@@ -1,0 +1,103 @@
+"""GPU parity against the committed golden vectors (no oracle needed at run time) and the
+faiss-shaped Python operators on the real HIP backend."""
+import warnings
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = Path(__file__).resolve().parent / "golden"
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def test_tokenizer_golden(be):
+    from audio_tokens_amd.ops import IndexFlatL2
+    g = np.load(G / "tokenizer.npz")
+    index = IndexFlatL2(64)
+    index.add(g["c"])
+    D, I = index.search(g["x"], 1)
+    assert I.dtype == np.int64 and D.dtype == np.float32 and I.shape == (4000, 1)
+    assert np.array_equal(I[:, 0], g["ids"]) and np.array_equal(bits(D[:, 0]), bits(g["dis"]))
+    D, I = index.search(g["x"][:7], 1)                       # n < 20: faiss' direct form
+    assert np.array_equal(I[:, 0], g["ids_small"]) and np.array_equal(bits(D[:, 0]), bits(g["dis_small"]))
+    # device tensors in -> device tensors out
+    Dt, It = index.search(torch.from_numpy(g["x"]).cuda(), 1)
+    assert It.is_cuda and np.array_equal(It.cpu().numpy()[:, 0], g["ids"])
+
+
+def test_kmeans_golden_all_cases(be):
+    from audio_tokens_amd.ops import Kmeans
+    g = np.load(G / "kmeans.npz")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        km = Kmeans(64, 64, niter=20)
+        km.train(g["a_x"])
+        assert np.array_equal(bits(km.centroids), bits(g["a_centroids"]))
+        assert [s["nsplit"] for s in km.iteration_stats] == list(g["a_nsplit"])
+        np.testing.assert_allclose(km.obj, g["a_obj"], rtol=2e-6)
+        assert np.array_equal(km._last_assign.cpu().numpy(), g["a_assign"])
+        kb = Kmeans(64, 48, niter=6)
+        kb.train(g["b_x"])                                   # empty clusters -> split_clusters every iteration
+        assert np.array_equal(bits(kb.centroids), bits(g["b_centroids"]))
+        assert [s["nsplit"] for s in kb.iteration_stats] == list(g["b_nsplit"])
+        kc = Kmeans(8, 64, niter=5)
+        kc.train(g["c_x"], init_centroids=g["c_init"])       # mt19937 subsample, generic-d kernels
+        assert np.array_equal(bits(kc.centroids), bits(g["c_centroids"]))
+
+
+def test_logmel_golden(be):
+    g = np.load(G / "logmel.npz")
+    for nm in (64, 128):
+        got = be.logmel(g["wave"], n_mels=nm).cpu().numpy()
+        ref = g[f"logmel_{nm}"]
+        P, Pr = 10.0 ** (got.astype(np.float64) / 10), 10.0 ** (ref.astype(np.float64) / 10)
+        tol = 2e-5 * Pr + 1e-9 * Pr.max(axis=-2, keepdims=True) + 1e-14
+        assert (np.abs(P - Pr) <= tol).all()
+        # a user-supplied filterbank (e.g. torchaudio's own) gives the same answer as the built-in
+        got2 = be.logmel(g["wave"], n_mels=nm, fb=g[f"fb_{nm}"]).cpu().numpy()
+        assert np.array_equal(bits(got2), bits(got))
+
+
+def test_logmel_spectrogram_operator(be):
+    from audio_tokens_amd.ops import LogMelSpectrogram
+    g = np.load(G / "logmel.npz")
+    op = LogMelSpectrogram(sample_rate=22050, n_mels=64, n_fft=512, hop_length=128)
+    one = op(torch.from_numpy(g["wave"][:1]))                # [1, L] like the reference's call
+    assert tuple(one.shape) == (1, 64, 173)
+    allc = op(g["wave"])
+    assert np.array_equal(bits(allc[0].cpu().numpy()), bits(one[0].cpu().numpy()))
+
+
+def test_full_size_properties(be):
+    """BASELINE-size launch (2 097 152 x 64 vs 8192): size-independent checks."""
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    n, d, k = 2097152, 64, 8192
+    x = torch.nn.functional.normalize(torch.randn(n, d, device="cuda", generator=gen), dim=1)
+    c = torch.nn.functional.normalize(torch.randn(k, d, device="cuda", generator=gen), dim=1)
+    ids, dis = be.assign(x, c)
+    assert int(ids.min()) >= 0 and int(ids.max()) < k
+    # the reported distance is the distance to the reported centroid (recomputed in fp64)
+    sel = torch.randint(0, n, (20000,), device="cuda", generator=gen)
+    d64 = ((x[sel].double() - c[ids[sel]].double()) ** 2).sum(1)
+    assert float((dis[sel].double() - d64).abs().max()) < 5e-6
+    # no other centroid is closer (dense fp64 check on a sample)
+    sub = sel[:2000]
+    full = torch.cdist(x[sub].double(), c.double()) ** 2
+    assert float((d64[:2000] - full.min(1).values).max()) < 5e-6
+    # permuting the rows permutes the answer; a row that is a centroid maps to it with distance ~0
+    perm = torch.randperm(n, device="cuda", generator=gen)
+    ids_p, _ = be.assign(x[perm].contiguous(), c)
+    assert torch.equal(ids_p, ids[perm])
+    ids_c, dis_c = be.assign(c, c)
+    assert torch.equal(ids_c, torch.arange(k, device="cuda")) and float(dis_c.max()) < 1e-6
+    # centroid sums: totals are conserved and counts add up
+    part = be.centroid_accum(x, ids, k)
+    counts = part[k * d:]
+    assert float(counts.sum()) == n
+    tot = part[: k * d].view(k, d).double().sum(0)
+    assert float((tot - x.double().sum(0)).abs().max()) < 1e-2

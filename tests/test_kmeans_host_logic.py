@@ -1,0 +1,150 @@
+"""Host logic of audio_tokens_amd.ops.Kmeans / IndexFlatL2 (the FAISS training recipe and its
+data-parallel variant) driven with the CPU stand-in backend, against the oracle and the golden
+vectors.  Includes the world_size-2 gloo run of the sharded path."""
+import os
+import socket
+import warnings
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+G = Path(__file__).resolve().parent / "golden"
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.fixture()
+def cpu_be():
+    from oracle_backend import OracleBackend
+    return OracleBackend()
+
+
+def test_train_matches_golden_plain_and_split(cpu_be):
+    from audio_tokens_amd.ops import Kmeans
+    g = np.load(G / "kmeans.npz")
+    km = Kmeans(64, 64, niter=20, backend=cpu_be)
+    obj = km.train(g["a_x"])
+    assert np.array_equal(bits(km.centroids), bits(g["a_centroids"]))
+    assert [s["nsplit"] for s in km.iteration_stats] == list(g["a_nsplit"])
+    np.testing.assert_allclose(km.obj, g["a_obj"], rtol=2e-6)
+    np.testing.assert_allclose([s["imbalance_factor"] for s in km.iteration_stats], g["a_imbalance"], rtol=1e-12)
+    assert obj == pytest.approx(float(g["a_obj"][-1]), rel=2e-6)
+    assert km.index.ntotal == 64
+    kb = Kmeans(64, 48, niter=6, backend=cpu_be)
+    kb.train(g["b_x"])
+    assert np.array_equal(bits(kb.centroids), bits(g["b_centroids"]))
+    assert [s["nsplit"] for s in kb.iteration_stats] == list(g["b_nsplit"])
+
+
+def test_train_subsample_and_warm_start(cpu_be):
+    from audio_tokens_amd.ops import Kmeans
+    g = np.load(G / "kmeans.npz")
+    km = Kmeans(8, 64, niter=5, backend=cpu_be)
+    km.train(g["c_x"], init_centroids=g["c_init"])
+    assert np.array_equal(bits(km.centroids), bits(g["c_centroids"]))
+    # the reference's loop: train(batch0); train(batch1, init_centroids=kmeans.centroids)
+    km2 = Kmeans(8, 64, niter=5, backend=cpu_be)
+    km2.train(g["c_x"][:9000])
+    first = km2.centroids.copy()
+    km2.train(g["c_x"][9000:], init_centroids=km2.centroids)
+    import oracle
+    r1 = oracle.kmeans_train(g["c_x"][:9000], 64, niter=5)
+    r2 = oracle.kmeans_train(g["c_x"][9000:], 64, niter=5, init_centroids=r1.centroids)
+    assert np.array_equal(bits(first), bits(r1.centroids)) and np.array_equal(bits(km2.centroids), bits(r2.centroids))
+
+
+def test_train_error_behaviour(cpu_be):
+    from audio_tokens_amd.ops import Kmeans
+    x = np.random.default_rng(0).standard_normal((10, 4)).astype(np.float32)
+    with pytest.raises(RuntimeError, match="should be at least as large as number of clusters"):
+        Kmeans(4, 16, backend=cpu_be).train(x)
+    bad = x.copy(); bad[2, 1] = np.inf
+    with pytest.raises(RuntimeError, match="NaN's or Inf's"):
+        Kmeans(4, 4, backend=cpu_be).train(bad)
+    km = Kmeans(4, 10, niter=3, backend=cpu_be)       # n == k: points become centroids
+    km.train(x)
+    assert np.array_equal(km.centroids, x) and km.iteration_stats[0]["nsplit"] == 0
+    with pytest.raises(NotImplementedError):
+        Kmeans(4, 2, spherical=True, backend=cpu_be)
+
+
+def test_index_flat_l2(cpu_be):
+    from audio_tokens_amd.ops import IndexFlatL2
+    g = np.load(G / "tokenizer.npz")
+    index = IndexFlatL2(64, backend=cpu_be)
+    assert index.ntotal == 0
+    index.add(g["c"][:100]); index.add(g["c"][100:])
+    assert index.ntotal == 256
+    D, I = index.search(g["x"], 1)
+    assert D.shape == (4000, 1) and I.shape == (4000, 1) and I.dtype == np.int64 and D.dtype == np.float32
+    assert np.array_equal(I[:, 0], g["ids"]) and np.array_equal(bits(D[:, 0]), bits(g["dis"]))
+    with pytest.raises(NotImplementedError):
+        index.search(g["x"], 5)
+    index.reset()
+    assert index.ntotal == 0
+
+
+# ---- world_size 2 under gloo ------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, case, q):
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle_backend import OracleBackend
+        from audio_tokens_amd.ops import Kmeans
+        g = np.load(G / "kmeans.npz")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if case == "plain":
+                x, cut = g["a_x"], 1000
+                local = x[:cut] if rank == 0 else x[cut:]
+                km = Kmeans(64, 64, niter=20, distributed=True, backend=OracleBackend())
+                km.train(local)
+            else:  # subsampled: 20000 rows, k=64 -> 16384 rows kept, spread over both ranks
+                x, cut = g["c_x"], 12345
+                local = x[:cut] if rank == 0 else x[cut:]
+                km = Kmeans(8, 64, niter=5, distributed=True, backend=OracleBackend())
+                km.train(local, init_centroids=g["c_init"])
+        q.put((rank, km.centroids.copy(), [s["nsplit"] for s in km.iteration_stats], km.obj.copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["plain", "subsampled"])
+def test_sharded_kmeans_gloo_world2(case, oracle):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    g = np.load(G / "kmeans.npz")
+    assert np.array_equal(bits(res[0][1]), bits(res[1][1])), "ranks disagree"
+    if case == "plain":
+        assert np.array_equal(bits(res[0][1]), bits(g["d_centroids"]))   # oracle's two-shard variant
+        np.testing.assert_allclose(res[0][3], g["d_obj"], rtol=2e-6)
+    else:
+        shard = (np.arange(20000) >= 12345).astype(np.int32)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            r = oracle.kmeans_train(g["c_x"], 64, niter=5, init_centroids=g["c_init"], shard=shard, n_shards=2)
+        assert np.array_equal(bits(res[0][1]), bits(r.centroids))
