@@ -9,15 +9,19 @@
 //   dis(i,j) = max(0, (xn + cn) - 2*ip)            one rounding for the add, one for the fma
 //   ids[i]   = lowest j with minimal dis, dist[i] = that dis
 //
-// Data flow.  The centroid table is re-laid once per call into 64-centroid tiles whose rows are
-// already in LDS order (k split even/odd per 8 features so that one ds_read_b128 feeds four
+// Data flow.  The centroid table is re-laid once per call into tiles of 32*NA centroids whose rows
+// are already in LDS order (k split even/odd per 8 features so that one ds_read_b128 feeds four
 // consecutive MFMA k-steps, 16-byte chunks XOR-swizzled by row so the reads are conflict free),
-// each tile followed by its 64 squared norms.  A workgroup of 4 waves streams every tile through a
+// each tile followed by its squared norms.  A workgroup of 4 waves streams every tile through a
 // double-buffered LDS copy while each wave keeps its 32*NB rows of x in registers for the whole
 // sweep (B operand: lane l holds x[row l&31][k = 2s + (l>>5)]); the 32x32 accumulator puts the x
 // row on the lane and 16 centroids in the registers, so the running arg-min is lane-local and the
-// two half-waves are merged once at the end.  HBM traffic: x once (4d B/row) + 12 B/row out;
+// two half-waves are merged once at the end.  The arg-min of a finished accumulator is scheduled
+// between the MFMAs of the next one, including across the tile boundary (the last accumulator of
+// a tile is carried into the next loop iteration).  HBM traffic: x once (4d B/row) + 12 B/row out;
 // the centroid image (k*d*4 B) is L2/Infinity-Cache resident.  Bound: fp32 MFMA (2*d*k flop/row).
+#include <cstdlib>
+
 #include "at_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -25,25 +29,27 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int CT = 64;        // centroid rows per image tile
-constexpr int WG = 256;       // threads per workgroup (4 waves)
+constexpr int WG = 256;    // threads per workgroup (4 waves)
+constexpr int CN_PAD = 256;  // floats reserved per tile for the squared norms (whole 1 KiB pieces)
 
-__host__ __device__ constexpr int tile_floats(int dp) { return CT * dp + CT; }
+__host__ __device__ constexpr int tile_rows(int na) { return 32 * na; }
+__host__ __device__ constexpr int tile_floats(int dp, int na) { return tile_rows(na) * dp + CN_PAD; }
 
 // ---------------------------------------------------------------------------------------------
-// Centroid image: tile t holds rows t*64 .. t*64+63.  Row r, 16-byte chunk pc (physical) holds
-// logical chunk lc = pc ^ (r & 15); lc = 2q + h holds features 8q + {0,2,4,6} + h.  Features
-// >= d and rows >= k are zero; |c|^2 of a row >= k is +inf so it can never win.
+// Centroid image: tile t holds rows t*R .. t*R+R-1 (R = 32*na).  Row r, 16-byte chunk pc
+// (physical) holds logical chunk lc = pc ^ (r & 15); lc = 2q + h holds features 8q + {0,2,4,6} + h.
+// Features >= d and rows >= k are zero; |c|^2 of a row >= k is +inf so it can never win.
 __global__ void __launch_bounds__(WG) prep_centroids_kernel(const float* __restrict__ c, int k, int d,
-                                                            int dp, float* __restrict__ img) {
+                                                            int dp, int na, float* __restrict__ img) {
     const int t = blockIdx.x;
-    float* out = img + (size_t)t * tile_floats(dp);
+    const int R = tile_rows(na);
+    float* out = img + (size_t)t * tile_floats(dp, na);
     const int chunks_per_row = dp / 4;
-    for (int e = threadIdx.x; e < CT * chunks_per_row; e += WG) {
+    for (int e = threadIdx.x; e < R * chunks_per_row; e += WG) {
         const int r = e / chunks_per_row, pc = e % chunks_per_row;
         const int lc = pc ^ (r & 15);
         const int q = lc >> 1, h = lc & 1;
-        const int row = t * CT + r;
+        const int row = t * R + r;
         f32x4 v;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -52,20 +58,19 @@ __global__ void __launch_bounds__(WG) prep_centroids_kernel(const float* __restr
         }
         *reinterpret_cast<f32x4*>(out + (size_t)r * dp + pc * 4) = v;
     }
-    if (threadIdx.x < CT) {
-        const int row = t * CT + threadIdx.x;
+    for (int r = threadIdx.x; r < CN_PAD; r += WG) {
+        const int row = t * R + r;
         float nrm = __builtin_inff();
-        if (row < k) {
+        if (r < R && row < k) {
             nrm = 0.0f;
             for (int f = 0; f < d; f++) {
                 const float v = c[(size_t)row * d + f];
                 nrm = __builtin_fmaf(v, v, nrm);
             }
         }
-        out[CT * dp + threadIdx.x] = nrm;
+        out[R * dp + r] = nrm;
     }
 }
-
 
 // One arg-min step with the compare mask kept in VCC (three VALU ops, no SGPR pair to carry):
 //   keep = !(dis < bd);  bd = keep ? bd : dis;  br = keep ? br : R
@@ -92,24 +97,39 @@ __device__ __forceinline__ void epilogue_from(float& bd, unsigned& br, const f32
     }
 }
 
-__device__ __forceinline__ void epilogue16(float& bd, unsigned& br, const f32x16& acc, float xn,
-                                           const f32x4 (&cnv)[4]) {
+// Running arg-min over one finished accumulator (this lane's 16 centroids, ascending index).
+__device__ __forceinline__ void epilogue16(float& bestd, unsigned& bestc, const f32x16& acc, float xn,
+                                           const f32x4 (&cnv)[4], unsigned codebase) {
+    float bd = bestd;
+    unsigned br = 16u;  // 16 = "no improvement from this accumulator"
     epilogue_from<0>(bd, br, acc, xn, cnv);
+    bestd = bd;
+    bestc = br != 16u ? (codebase | br) : bestc;
+}
+
+// 1 KiB of global memory -> LDS without passing through registers (global_load_lds_dwordx4):
+// lane l's 16 bytes land at lds_wave_base + 16*l.
+__device__ __forceinline__ void dma_1k(const float* gsrc_lane, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)gsrc_lane,
+        (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int D, int NB>
-__global__ void __launch_bounds__(WG, 2)
+template <int D, int NB, int NA, bool DMA, int WAVES_PER_SIMD>
+__global__ void __launch_bounds__(WG, WAVES_PER_SIMD)
 assign_mfma_kernel(const float* __restrict__ X, long n, const float* __restrict__ img, int ntiles,
                    long* __restrict__ ids, float* __restrict__ dist) {
-    constexpr int TILE_F = tile_floats(D);
+    constexpr int R = tile_rows(NA);
+    constexpr int TILE_F = tile_floats(D, NA);
     constexpr int NV = TILE_F / 4;               // float4 per tile image
-    constexpr int VPT = (NV + WG - 1) / WG;      // float4 staged per thread
+    constexpr int VPT = (NV + WG - 1) / WG;      // float4 staged per thread (register staging)
+    constexpr int PIECES = TILE_F / 256;         // 1 KiB pieces per tile (DMA staging)
     extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 * TILE_F floats
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31;   // x row within a 32-row tile == accumulator column
     const int h = lane >> 5;   // which k of each MFMA k-pair this lane feeds
     const long row0 = ((long)blockIdx.x * 4 + wave) * (32 * NB);
@@ -151,8 +171,18 @@ assign_mfma_kernel(const float* __restrict__ X, long n, const float* __restrict_
     }
 
     // ---- stage tile 0 ----
-    f32x4 pf[VPT];
-    {
+    auto stage_dma = [&](int tile, float* dst) {
+        const float* src = img + (size_t)tile * TILE_F;
+#pragma unroll
+        for (int p0 = 0; p0 < PIECES; p0 += 4) {
+            const int p = p0 + wave;
+            if (p < PIECES) dma_1k(src + p * 256 + lane * 4, dst + p * 256);
+        }
+    };
+    f32x4 pf[DMA ? 1 : VPT];
+    if constexpr (DMA) {
+        stage_dma(0, smem);
+    } else {
         const f32x4* src = reinterpret_cast<const f32x4*>(img);
 #pragma unroll
         for (int v = 0; v < VPT; v++) {
@@ -162,28 +192,39 @@ assign_mfma_kernel(const float* __restrict__ X, long n, const float* __restrict_
     }
     __syncthreads();
 
+    // the last accumulator of a tile is finished inside the next iteration
+    f32x16 accP = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x4 cnP[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) cnP[g] = {__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
+    unsigned codeP = 0u;
+
     const int swz = j & 15;
     for (int ct = 0; ct < ntiles; ct++) {
         const float* cur = smem + (ct & 1) * TILE_F;
         const bool more = ct + 1 < ntiles;
         if (more) {
-            const f32x4* src = reinterpret_cast<const f32x4*>(img + (size_t)(ct + 1) * TILE_F);
+            if constexpr (DMA) {
+                stage_dma(ct + 1, smem + ((ct + 1) & 1) * TILE_F);
+            } else {
+                const f32x4* src = reinterpret_cast<const f32x4*>(img + (size_t)(ct + 1) * TILE_F);
 #pragma unroll
-            for (int v = 0; v < VPT; v++) {
-                const int e = tid + v * WG;
-                if (e < NV) pf[v] = src[e];
+                for (int v = 0; v < VPT; v++) {
+                    const int e = tid + v * WG;
+                    if (e < NV) pf[v] = src[e];
+                }
             }
         }
 
 #pragma unroll
-        for (int a = 0; a < 2; a++) {
+        for (int a = 0; a < NA; a++) {
             // |c|^2 of this lane's 16 accumulator rows: rows a*32 + 8g + 4h + (0..3)
             f32x4 cnv[4];
 #pragma unroll
             for (int g = 0; g < 4; g++)
-                cnv[g] = *reinterpret_cast<const f32x4*>(cur + CT * D + a * 32 + 8 * g + 4 * h);
+                cnv[g] = *reinterpret_cast<const f32x4*>(cur + R * D + a * 32 + 8 * g + 4 * h);
             const float* arow = cur + (a * 32 + j) * D;
-            const unsigned codebase = (unsigned)(ct * 2 + a) * 16u;
+            const unsigned codebase = (unsigned)(ct * NA + a) * 16u;
 #pragma unroll
             for (int b = 0; b < NB; b++) {
                 f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -196,25 +237,32 @@ assign_mfma_kernel(const float* __restrict__ X, long n, const float* __restrict_
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], xr[b][4 * q + 2], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], xr[b][4 * q + 3], acc, 0, 0, 0);
                 }
-                // running arg-min over this lane's 16 centroids (ascending index == ascending r)
-                float bd = bestd[b];
-                unsigned br = 16u;  // 16 = "no improvement in this job"
-                epilogue16(bd, br, acc, xn[b], cnv);
-                bestd[b] = bd;
-                bestc[b] = br != 16u ? (codebase | br) : bestc[b];
+                if (a == 0 && b == 0)  // previous tile's last accumulator (no-op on the first tile)
+                    epilogue16(bestd[NB - 1], bestc[NB - 1], accP, xn[NB - 1], cnP, codeP);
+                if (a == NA - 1 && b == NB - 1) {
+                    accP = acc;
+#pragma unroll
+                    for (int g = 0; g < 4; g++) cnP[g] = cnv[g];
+                    codeP = codebase;
+                } else {
+                    epilogue16(bestd[b], bestc[b], acc, xn[b], cnv, codebase);
+                }
             }
         }
 
-        if (more) {
-            f32x4* dst = reinterpret_cast<f32x4*>(smem + ((ct + 1) & 1) * TILE_F);
+        if constexpr (!DMA) {
+            if (more) {
+                f32x4* dst = reinterpret_cast<f32x4*>(smem + ((ct + 1) & 1) * TILE_F);
 #pragma unroll
-            for (int v = 0; v < VPT; v++) {
-                const int e = tid + v * WG;
-                if (e < NV) dst[e] = pf[v];
+                for (int v = 0; v < VPT; v++) {
+                    const int e = tid + v * WG;
+                    if (e < NV) dst[e] = pf[v];
+                }
             }
         }
-        __syncthreads();
+        __syncthreads();  // (with LDS-DMA in flight hipcc makes this vmcnt(0) + s_barrier)
     }
+    epilogue16(bestd[NB - 1], bestc[NB - 1], accP, xn[NB - 1], cnP, codeP);
 
     // ---- merge the two half-waves (rows 4h + ... of every 8-row group) and store ----
 #pragma unroll
@@ -241,8 +289,8 @@ assign_mfma_kernel(const float* __restrict__ X, long n, const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// Any d (v1 fallback: scalar fmaf chains, one thread per row, centroids and norms from the same
-// image so the arithmetic is the same as the MFMA path).  Used when d is not 64 or 128.
+// Any d (v1 fallback: scalar fmaf chains, one thread per row; same arithmetic as the MFMA path).
+// Used when d is not 64 or 128.
 __global__ void __launch_bounds__(WG)
 assign_generic_kernel(const float* __restrict__ X, long n, int d, const float* __restrict__ C,
                       const float* __restrict__ cn, int k, long* __restrict__ ids,
@@ -301,22 +349,35 @@ __global__ void assign_small_kernel(const float* __restrict__ X, int n, int d,
     if (dist) dist[i] = best;
 }
 
-template <int D, int NB>
-int launch_mfma(const float* x, int64_t n, const float* img, int ntiles, int64_t* ids, float* dist,
+template <int D, int NB, int NA, bool DMA, int WPS>
+int launch_mfma(at_ctx* ctx, const float* x, int64_t n, const float* c, int k, int64_t* ids, float* dist,
                 hipStream_t stream) {
-    const size_t lds = 2 * sizeof(float) * tile_floats(D);
+    const int ntiles = (k + tile_rows(NA) - 1) / tile_rows(NA);
+    const size_t img_bytes = sizeof(float) * (size_t)ntiles * tile_floats(D, NA);
+    float* img = static_cast<float*>(at_ws(ctx, WS_CENT_IMG, img_bytes, stream));
+    if (!img) return AT_E_NOMEM;
+    hipLaunchKernelGGL(prep_centroids_kernel, dim3(ntiles), dim3(WG), 0, stream, c, k, D, D, NA, img);
+    AT_LAUNCH_CHECK();
+    const size_t lds = 2 * sizeof(float) * tile_floats(D, NA);
     const int64_t rows_per_wg = 4 * 32 * NB;
     const int64_t grid = (n + rows_per_wg - 1) / rows_per_wg;
     static bool attr_set = false;
     if (!attr_set) {
-        AT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&assign_mfma_kernel<D, NB>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AT_HIP(hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&assign_mfma_kernel<D, NB, NA, DMA, WPS>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((assign_mfma_kernel<D, NB>), dim3((unsigned)grid), dim3(WG), lds, stream, x,
-                       (long)n, img, ntiles, reinterpret_cast<long*>(ids), dist);
+    hipLaunchKernelGGL((assign_mfma_kernel<D, NB, NA, DMA, WPS>), dim3((unsigned)grid), dim3(WG), lds,
+                       stream, x, (long)n, img, ntiles, reinterpret_cast<long*>(ids), dist);
     AT_LAUNCH_CHECK();
     return AT_OK;
+}
+
+// Development switch (A/B of kernel shapes on the GPU box): AT_ASSIGN_VARIANT, default 0.
+int assign_variant() {
+    const char* e = std::getenv("AT_ASSIGN_VARIANT");
+    return e ? std::atoi(e) : 0;
 }
 
 }  // namespace
@@ -340,14 +401,15 @@ extern "C" int at_assign_f32(at_ctx* ctx, const float* x, int64_t n, int d, cons
 
     if (d == 64 || d == 128) {
         AT_REQUIRE(at_aligned16(x), "at_assign_f32: x must be 16-byte aligned");
-        const int ntiles = (k + CT - 1) / CT;
-        const size_t img_bytes = sizeof(float) * (size_t)ntiles * tile_floats(d);
-        float* img = static_cast<float*>(at_ws(ctx, WS_CENT_IMG, img_bytes, stream));
-        if (!img) return AT_E_NOMEM;
-        hipLaunchKernelGGL(prep_centroids_kernel, dim3(ntiles), dim3(WG), 0, stream, c, k, d, d, img);
-        AT_LAUNCH_CHECK();
-        if (d == 64) return launch_mfma<64, 2>(x, n, img, ntiles, ids, dist, stream);
-        return launch_mfma<128, 1>(x, n, img, ntiles, ids, dist, stream);
+        // Shipped shapes: LDS-DMA staging, 128-centroid tiles at d=64 (64 at d=128), 2 waves/SIMD.
+        // AT_ASSIGN_VARIANT=1 selects the register-staged 64-centroid-tile kernel (A/B aid).
+        const int v = assign_variant();
+        if (d == 64) {
+            if (v == 1) return launch_mfma<64, 2, 2, false, 2>(ctx, x, n, c, k, ids, dist, stream);
+            return launch_mfma<64, 2, 4, true, 2>(ctx, x, n, c, k, ids, dist, stream);
+        }
+        if (v == 1) return launch_mfma<128, 1, 2, false, 2>(ctx, x, n, c, k, ids, dist, stream);
+        return launch_mfma<128, 1, 2, true, 2>(ctx, x, n, c, k, ids, dist, stream);
     }
 
     float* cn = static_cast<float*>(at_ws(ctx, WS_CENT_IMG, sizeof(float) * (size_t)k, stream));

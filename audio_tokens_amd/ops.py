@@ -71,7 +71,10 @@ class LogMelSpectrogram:
 
 
 class _Dist:
-    """Thin view of torch.distributed for the sharded k-means (one process per GPU, RCCL)."""
+    """Thin view of torch.distributed for the sharded k-means (one process per GPU, RCCL).
+
+    With the gloo backend (CPU tests, or several test ranks sharing one GPU) device tensors are
+    staged through the host; with nccl (= RCCL) the collectives run on the device tensors."""
 
     def __init__(self, enabled, group=None):
         import torch.distributed as dist
@@ -80,42 +83,55 @@ class _Dist:
         self.group = group
         self.world = dist.get_world_size(group) if self.on else 1
         self.rank = dist.get_rank(group) if self.on else 0
+        self.host_staged = self.on and dist.get_backend(group) == "gloo"
+
+    def _all_reduce(self, t, op):
+        if self.host_staged and t.device.type != "cpu":
+            h = t.cpu()
+            self.dist.all_reduce(h, op=op, group=self.group)
+            t.copy_(h)
+        else:
+            self.dist.all_reduce(t, op=op, group=self.group)
+        return t
+
+    def _all_gather(self, t):
+        """t [m] -> [world * m], rank order."""
+        if self.host_staged and t.device.type != "cpu":
+            h = t.cpu()
+            out = torch.empty(self.world * h.numel(), dtype=h.dtype)
+            self.dist.all_gather_into_tensor(out, h.reshape(-1), group=self.group)
+            return out.to(t.device)
+        out = torch.empty(self.world * t.numel(), dtype=t.dtype, device=t.device)
+        self.dist.all_gather_into_tensor(out, t.reshape(-1), group=self.group)
+        return out
 
     def all_gather_sizes(self, n_loc, device):
         if not self.on:
             return [n_loc]
-        t = torch.tensor([n_loc], dtype=torch.int64, device=device)
-        out = torch.empty(self.world, dtype=torch.int64, device=device)
-        self.dist.all_gather_into_tensor(out, t, group=self.group)
+        out = self._all_gather(torch.tensor([n_loc], dtype=torch.int64, device=device))
         return [int(v) for v in out.cpu()]
 
     def any_flag(self, flag: bool, device) -> bool:
         if not self.on:
             return flag
         t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
-        return bool(t.item())
+        return bool(self._all_reduce(t, self.dist.ReduceOp.MAX).item())
 
     def all_gather_parts(self, part):
         """part [m] float32 -> [world, m], rank order."""
         if not self.on:
             return part.unsqueeze(0)
-        out = torch.empty(self.world * part.numel(), dtype=part.dtype, device=part.device)
-        self.dist.all_gather_into_tensor(out, part.reshape(-1), group=self.group)
-        return out.view(self.world, part.numel())
+        return self._all_gather(part).view(self.world, part.numel())
 
     def sum_bits(self, rows):
         """Exact merge of float32 rows of which exactly one rank holds a non-zero copy."""
         if not self.on:
             return rows
         bits = rows.view(torch.int32)
-        self.dist.all_reduce(bits, op=self.dist.ReduceOp.SUM, group=self.group)
-        return bits.view(torch.float32)
+        return self._all_reduce(bits, self.dist.ReduceOp.SUM).view(torch.float32)
 
     def sum_f64(self, v):
-        if self.on:
-            self.dist.all_reduce(v, op=self.dist.ReduceOp.SUM, group=self.group)
-        return v
+        return self._all_reduce(v, self.dist.ReduceOp.SUM) if self.on else v
 
 
 _PERM_CACHE: "OrderedDict[tuple, np.ndarray]" = OrderedDict()

@@ -1,0 +1,100 @@
+"""The sharded k-means on real HIP kernels with world_size 2: two ranks share cuda:0 and exchange
+their partials through gloo (host-staged), which exercises the same host logic and the same
+kernels as one-rank-per-GPU under RCCL.  Result must equal the oracle's two-shard variant, bit for
+bit, on both ranks."""
+import os
+import socket
+import warnings
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+G = Path(__file__).resolve().parent / "golden"
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        from audio_tokens_amd.ops import Kmeans
+        from audio_tokens_amd.pipeline import DevicePipeline
+        from audio_tokens_amd.synth import synth_clips
+        g = np.load(G / "kmeans.npz")
+        out = {}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            x, cut = g["a_x"], 1000
+            km = Kmeans(64, 64, niter=20, distributed=True)
+            km.train(x[:cut] if rank == 0 else x[cut:])
+            out["plain"] = km.centroids.copy()
+            x, cut = g["c_x"], 12345
+            kc = Kmeans(8, 64, niter=5, distributed=True)
+            kc.train(x[:cut] if rank == 0 else x[cut:], init_centroids=g["c_init"])
+            out["sub"] = kc.centroids.copy()
+            # whole device pipeline, 2 ranks x 3 clips
+            wave = synth_clips(6, L=22050 * 2, seed=11, device="cuda")
+            mine = wave[rank * 3:(rank + 1) * 3]
+            res = DevicePipeline(n_mels=64, vocab_size=32, niter=4, clustering_batch_size=6,
+                                 distributed=True).run(mine[:2], mine[2:])
+            out["pipe_centroids"] = res.centroids.cpu().numpy()
+            out["pipe_tokens"] = res.tokens_train.cpu().numpy()
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu(oracle, be):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    g = np.load(G / "kmeans.npz")
+    assert np.array_equal(bits(res[0]["plain"]), bits(res[1]["plain"]))
+    assert np.array_equal(bits(res[0]["plain"]), bits(g["d_centroids"]))
+    shard = (np.arange(20000) >= 12345).astype(np.int32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r = oracle.kmeans_train(g["c_x"], 64, niter=5, init_centroids=g["c_init"], shard=shard, n_shards=2)
+    assert np.array_equal(bits(res[0]["sub"]), bits(r.centroids)) and np.array_equal(bits(res[1]["sub"]), bits(r.centroids))
+    # pipeline: both ranks hold the same centroids; the oracle reproduces them from the same frames
+    assert np.array_equal(bits(res[0]["pipe_centroids"]), bits(res[1]["pipe_centroids"]))
+    from audio_tokens_amd.synth import synth_clips
+    wave = synth_clips(6, L=22050 * 2, seed=11, device="cuda")
+    frames = be.logmel(wave, frame_major=True, l2norm=True).cpu().numpy()
+    T = frames.shape[0] // 6
+    # global batch = rank 0's two train clips then rank 1's two train clips (clips 0,1,3,4)
+    xb = np.concatenate([frames[0:2 * T], frames[3 * T:5 * T]])
+    sh = np.repeat(np.array([0, 1], np.int32), 2 * T)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ro = oracle.kmeans_train(xb, 32, niter=4, shard=sh, n_shards=2)
+    cent = oracle.l2norm_rows(ro.centroids)
+    assert np.array_equal(bits(res[0]["pipe_centroids"]), bits(cent))
+    ids, _ = oracle.assign(frames, cent)
+    assert np.array_equal(res[0]["pipe_tokens"], ids[0:2 * T]) and np.array_equal(res[1]["pipe_tokens"], ids[3 * T:5 * T])
