@@ -27,7 +27,7 @@ struct at_ctx {
     void* ws[WS_NSLOTS];
     size_t ws_bytes[WS_NSLOTS];
     // cached description of what WS_LOGMEL_FB currently holds
-    int fb_sr, fb_nfft, fb_nmels;
+    int fb_sr, fb_nfft, fb_nmels, fb_nw;
     const float* fb_user;
 };
 

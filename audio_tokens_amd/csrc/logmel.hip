@@ -39,6 +39,8 @@ struct LogmelParams {
     const int* fb_len;      // [n_mels]
     const int* fb_off;      // [n_mels] offset into fb_wts
     const float* fb_wts;    // concatenated non-zero bands
+    int fb_nw;              // number of weights; tables are copied to LDS when fb_lds != 0
+    int fb_lds;
     float* out;
     int frame_major, fuse_l2norm;
 };
@@ -54,6 +56,18 @@ __global__ void __launch_bounds__(WG, 2) logmel_kernel(LogmelParams p) {
     float* samp = tabs + TAB_FLOATS;               // nsamp (rounded up to 4)
     float* work = samp + ((nsamp + 3) & ~3);       // 16 frames x FRAME_LDS_FLOATS
     float* ostage = work + 16 * FRAME_LDS_FLOATS;  // fpb x opitch  (+ fpb denominators)
+    int* fbi = reinterpret_cast<int*>(ostage + p.fpb * opitch + p.fpb);  // start | len | off | weights
+    const int* fb_start = p.fb_start;
+    const int* fb_len = p.fb_len;
+    const int* fb_off = p.fb_off;
+    const float* fb_wts = p.fb_wts;
+    if (p.fb_lds) {
+        for (int i = tid; i < 3 * p.n_mels + p.fb_nw; i += WG) fbi[i] = p.fb_start[i];  // one contiguous blob
+        fb_start = fbi;
+        fb_len = fbi + p.n_mels;
+        fb_off = fbi + 2 * p.n_mels;
+        fb_wts = reinterpret_cast<const float*>(fbi + 3 * p.n_mels);
+    }
 
     const long clip = blockIdx.y;
     const int t0 = blockIdx.x * p.fpb;
@@ -91,7 +105,7 @@ __global__ void __launch_bounds__(WG, 2) logmel_kernel(LogmelParams p) {
         for (int i = 0; i < n_mel_iter; i++) {
             const int m = l16 + 16 * i;
             if (m < p.n_mels) {
-                float s = mel_band(mybuf, p.fb_start[m], p.fb_len[m], p.fb_wts + p.fb_off[m]);
+                float s = mel_band(mybuf, fb_start[m], fb_len[m], fb_wts + fb_off[m]);
                 // clamp(x, 1e-10) then 10*log10: a clamped bin is exactly -100 dB (what a correctly
                 // rounded log10 of 1e-10f gives; the device log10f is 1 ulp off there)
                 ostage[f * opitch + m] = s > 1e-10f ? 10.0f * log10f(s) : -100.0f;
@@ -127,7 +141,8 @@ __global__ void __launch_bounds__(WG, 2) logmel_kernel(LogmelParams p) {
 
 // Host side: window / twiddles / banded filterbank, uploaded once per (sr, n_mels, fb) change.
 int build_tables(at_ctx* ctx, int sample_rate, int n_mels, const float* fb_user_dev, hipStream_t stream,
-                 const float** tabs, const int** st, const int** ln, const int** of, const float** wt) {
+                 const float** tabs, const int** st, const int** ln, const int** of, const float** wt,
+                 int* n_weights) {
     const bool cached = ctx->ws[WS_LOGMEL_FB] && ctx->fb_sr == sample_rate && ctx->fb_nfft == NFFT &&
                         ctx->fb_nmels == n_mels && ctx->fb_user == fb_user_dev;
     std::vector<float> fb((size_t)NBIN * n_mels);
@@ -162,8 +177,9 @@ int build_tables(at_ctx* ctx, int sample_rate, int n_mels, const float* fb_user_
         std::vector<float> t(TAB_FLOATS);
         for (int i = 0; i < NFFT; i++) t[TAB_WIN + i] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * i / NFFT));
         for (int j = 0; j < 256; j++) {
-            t[TAB_TW256 + 2 * j] = (float)std::cos(2.0 * M_PI * j / 256.0);
-            t[TAB_TW256 + 2 * j + 1] = (float)-std::sin(2.0 * M_PI * j / 256.0);
+            const int e = (j / 16) * (j % 16);  // layout [k1][m2] -> W256^(m2*k1) (logmel_core.h phase1)
+            t[TAB_TW256 + 2 * j] = (float)std::cos(2.0 * M_PI * e / 256.0);
+            t[TAB_TW256 + 2 * j + 1] = (float)-std::sin(2.0 * M_PI * e / 256.0);
             t[TAB_TW512 + 2 * j] = (float)std::cos(2.0 * M_PI * j / 512.0);
             t[TAB_TW512 + 2 * j + 1] = (float)-std::sin(2.0 * M_PI * j / 512.0);
         }
@@ -179,6 +195,7 @@ int build_tables(at_ctx* ctx, int sample_rate, int n_mels, const float* fb_user_
         AT_HIP(hipStreamSynchronize(stream));
         AT_HIP(hipMemcpy(base, blob.data(), bytes, hipMemcpyHostToDevice));
         ctx->fb_sr = sample_rate; ctx->fb_nfft = NFFT; ctx->fb_nmels = n_mels; ctx->fb_user = fb_user_dev;
+        ctx->fb_nw = (int)wts.size();
     } else {
         base = static_cast<char*>(ctx->ws[WS_LOGMEL_FB]);
     }
@@ -186,6 +203,7 @@ int build_tables(at_ctx* ctx, int sample_rate, int n_mels, const float* fb_user_
     const int* ints = reinterpret_cast<const int*>(base + sizeof(float) * TAB_FLOATS);
     *st = ints; *ln = ints + n_mels; *of = ints + 2 * n_mels;
     *wt = reinterpret_cast<const float*>(ints + 3 * n_mels);
+    *n_weights = ctx->fb_nw;
     return AT_OK;
 }
 
@@ -211,7 +229,7 @@ extern "C" int at_logmel_f32(at_ctx* ctx, const float* wave, int64_t n_clips, in
 
     LogmelParams p;
     int rc = build_tables(ctx, sample_rate, n_mels, fb_or_null, stream, &p.tabs, &p.fb_start, &p.fb_len,
-                          &p.fb_off, &p.fb_wts);
+                          &p.fb_off, &p.fb_wts, &p.fb_nw);
     if (rc) return rc;
     const int64_t T = at_num_frames(L, hop);
     AT_REQUIRE(T < (1LL << 31), "at_logmel_f32: too many frames per clip");
@@ -221,8 +239,11 @@ extern "C" int at_logmel_f32(at_ctx* ctx, const float* wave, int64_t n_clips, in
     p.out = out; p.frame_major = layout == AT_LAYOUT_FRAME_MAJOR; p.fuse_l2norm = fuse_l2norm;
 
     const int nsamp = (p.fpb - 1) * hop + NFFT;
-    const size_t lds = sizeof(float) * ((size_t)TAB_FLOATS + ((nsamp + 3) & ~3) + 16 * FRAME_LDS_FLOATS +
-                                        (size_t)p.fpb * (n_mels + 1) + p.fpb);
+    size_t lds = sizeof(float) * ((size_t)TAB_FLOATS + ((nsamp + 3) & ~3) + 16 * FRAME_LDS_FLOATS +
+                                  (size_t)p.fpb * (n_mels + 1) + p.fpb);
+    // the banded filterbank rides in LDS too unless a dense user filterbank makes it too big
+    p.fb_lds = (3 * (size_t)n_mels + p.fb_nw) * 4 <= 12 * 1024;
+    if (p.fb_lds) lds += (3 * (size_t)n_mels + p.fb_nw) * 4;
     AT_REQUIRE(lds <= 160 * 1024, "at_logmel_f32: n_mels=%d needs %zu bytes of LDS", n_mels, lds);
     static size_t attr_lds = 0;
     if (lds > attr_lds) {

@@ -80,7 +80,8 @@ AT_HD void dft16(cpx (&v)[16]) {
 
 // Phase 1, lane l = m2: windowed samples -> column FFT -> W256 twiddle -> transpose buffer.
 //   frame : the 512 samples of this frame (already reflect-padded), win : 512 window values,
-//   tw256 : 256 x (cos, -sin) of 2*pi*j/256, ebuf : FRAME_LDS_FLOATS floats.
+//   tw256 : 16 x 16 x (cos, -sin): entry [k1][m2] = W256^(m2*k1), so the 16 lanes of a frame read
+//           consecutive words; ebuf : FRAME_LDS_FLOATS floats.
 AT_HD void phase1(int l, const float* frame, const float* win, const float* tw256, float* ebuf) {
     cpx v[16];
 #pragma unroll
@@ -91,7 +92,7 @@ AT_HD void phase1(int l, const float* frame, const float* win, const float* tw25
     dft16(v);  // v[k1]
 #pragma unroll
     for (int k1 = 0; k1 < 16; k1++) {
-        const int j = l * k1;  // <= 225
+        const int j = k1 * 16 + l;
         const cpx w = {tw256[2 * j], tw256[2 * j + 1]};
         const cpx y = k1 == 0 ? v[0] : cmul(v[k1], w);
         ebuf[2 * (k1 * EPITCH + l)] = y.re;

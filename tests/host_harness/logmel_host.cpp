@@ -11,8 +11,9 @@ using namespace logmel;
 extern "C" void logmel_host_power(const float* frame /*512*/, const float* win /*512*/, float* power /*257*/) {
     std::vector<float> tw256(512), tw512(512), ebuf(FRAME_LDS_FLOATS), zbuf(512);
     for (int j = 0; j < 256; j++) {
-        tw256[2 * j] = (float)std::cos(2.0 * M_PI * j / 256.0);
-        tw256[2 * j + 1] = (float)-std::sin(2.0 * M_PI * j / 256.0);
+        const int e = (j / 16) * (j % 16);  // [k1][m2] -> W256^(m2*k1)
+        tw256[2 * j] = (float)std::cos(2.0 * M_PI * e / 256.0);
+        tw256[2 * j + 1] = (float)-std::sin(2.0 * M_PI * e / 256.0);
         tw512[2 * j] = (float)std::cos(2.0 * M_PI * j / 512.0);
         tw512[2 * j + 1] = (float)-std::sin(2.0 * M_PI * j / 512.0);
     }
