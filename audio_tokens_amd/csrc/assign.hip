@@ -289,8 +289,190 @@ assign_mfma_kernel(const float* __restrict__ X, long n, const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// Any d (v1 fallback: scalar fmaf chains, one thread per row; same arithmetic as the MFMA path).
-// Used when d is not 64 or 128.
+// Any d that is a multiple of 4 (n_mels other than 64/128, use_convolution's d = 10*n_mels):
+// the same MFMA sweep with the feature axis cut into chunks of 64.  The NA*NB accumulators of a
+// centroid tile stay live across the chunks (so every inner product is still ONE ascending fmaf
+// chain); the centroid image is laid out [tile][chunk][row][64 swizzled] and streamed through LDS
+// one (tile, chunk) piece at a time; the x chunk of a wave's rows is re-read from L2 per piece.
+constexpr int DC = 64;  // features per chunk
+
+__global__ void __launch_bounds__(WG) prep_centroids_chunked_kernel(const float* __restrict__ c, int k,
+                                                                    int d, int nchunks, int na,
+                                                                    float* __restrict__ img) {
+    const int t = blockIdx.x;
+    const int R = tile_rows(na);
+    float* out = img + (size_t)t * ((size_t)R * DC * nchunks + CN_PAD);
+    const int chunks16 = DC / 4;  // 16-byte chunks per row piece
+    for (int e = threadIdx.x; e < nchunks * R * chunks16; e += WG) {
+        const int ch = e / (R * chunks16);
+        const int r = (e / chunks16) % R, pc = e % chunks16;
+        const int lc = pc ^ (r & 15);
+        const int q = lc >> 1, h = lc & 1;
+        const int row = t * R + r;
+        f32x4 v;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int f = ch * DC + 8 * q + 2 * u + h;
+            v[u] = (row < k && f < d) ? c[(size_t)row * d + f] : 0.0f;
+        }
+        *reinterpret_cast<f32x4*>(out + ((size_t)ch * R + r) * DC + pc * 4) = v;
+    }
+    for (int r = threadIdx.x; r < CN_PAD; r += WG) {
+        const int row = t * R + r;
+        float nrm = __builtin_inff();
+        if (r < R && row < k) {
+            nrm = 0.0f;
+            for (int f = 0; f < d; f++) {
+                const float v = c[(size_t)row * d + f];
+                nrm = __builtin_fmaf(v, v, nrm);
+            }
+        }
+        out[(size_t)R * DC * nchunks + r] = nrm;
+    }
+}
+
+template <int NB, int NA>
+__global__ void __launch_bounds__(WG, 2)
+assign_mfma_anyd_kernel(const float* __restrict__ X, long n, int d, int nchunks,
+                        const float* __restrict__ img, int ntiles, long* __restrict__ ids,
+                        float* __restrict__ dist) {
+    constexpr int R = tile_rows(NA);
+    constexpr int PIECE_F = R * DC;                 // floats of one (tile, chunk) piece
+    constexpr int BUF_F = PIECE_F + CN_PAD;         // + the norms behind the last chunk
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 * BUF_F floats
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31;
+    const int h = lane >> 5;
+    const long row0 = ((long)blockIdx.x * 4 + wave) * (32 * NB);
+    const size_t tile_f = (size_t)PIECE_F * nchunks + CN_PAD;
+
+    const float* xrow[NB];
+    float xn[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        long r = row0 + 32 * b + j;
+        if (r >= n) r = n - 1;
+        xrow[b] = X + r * d;
+        float nrm = 0.0f;
+        for (int f = 0; f < d; f += 4) {
+            const f32x4 u = *reinterpret_cast<const f32x4*>(xrow[b] + f);
+            nrm = __builtin_fmaf(u[0], u[0], nrm);
+            nrm = __builtin_fmaf(u[1], u[1], nrm);
+            nrm = __builtin_fmaf(u[2], u[2], nrm);
+            nrm = __builtin_fmaf(u[3], u[3], nrm);
+        }
+        xn[b] = nrm;
+    }
+
+    float bestd[NB];
+    unsigned bestc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        bestd[b] = __builtin_inff();
+        bestc[b] = 0xffffffffu;
+    }
+
+    // piece s = ct * nchunks + ch lives at img + ct*tile_f + ch*PIECE_F; the last chunk drags the
+    // norms along (they sit right behind it)
+    auto stage_dma = [&](int ct, int ch, float* dst) {
+        const float* src = img + (size_t)ct * tile_f + (size_t)ch * PIECE_F;
+        const int pieces = (ch == nchunks - 1 ? BUF_F : PIECE_F) / 256;
+        for (int p = wave; p < pieces; p += 4) dma_1k(src + p * 256 + lane * 4, dst + p * 256);
+    };
+    stage_dma(0, 0, smem);
+    __syncthreads();
+
+    const int swz = j & 15;
+    const int nstages = ntiles * nchunks;
+    int ct = 0, ch = 0;
+    f32x16 acc[NA][NB];
+    for (int s = 0; s < nstages; s++) {
+        const float* cur = smem + (s & 1) * BUF_F;
+        {
+            int nct = ct, nch = ch + 1;
+            if (nch == nchunks) { nch = 0; nct++; }
+            if (s + 1 < nstages) stage_dma(nct, nch, smem + ((s + 1) & 1) * BUF_F);
+        }
+        // this wave's x chunk (features ch*64 .. +63, zero past d) as the B operand
+        float xr[NB][DC / 2];
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+#pragma unroll
+            for (int q = 0; q < DC / 8; q++) {
+                const int f = ch * DC + 8 * q;
+                f32x4 u = {0, 0, 0, 0}, v = {0, 0, 0, 0};
+                if (f < d) u = *reinterpret_cast<const f32x4*>(xrow[b] + f);          // d % 4 == 0
+                if (f + 4 < d) v = *reinterpret_cast<const f32x4*>(xrow[b] + f + 4);
+                xr[b][4 * q + 0] = h ? u[1] : u[0];
+                xr[b][4 * q + 1] = h ? u[3] : u[2];
+                xr[b][4 * q + 2] = h ? v[1] : v[0];
+                xr[b][4 * q + 3] = h ? v[3] : v[2];
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < NA; a++) {
+            const float* arow = cur + (a * 32 + j) * DC;
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                f32x16 cacc = acc[a][b];
+                if (ch == 0) cacc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < DC / 8; q++) {
+                    const int pc = (2 * q + h) ^ swz;
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(arow + pc * 4);
+                    cacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], xr[b][4 * q + 0], cacc, 0, 0, 0);
+                    cacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], xr[b][4 * q + 1], cacc, 0, 0, 0);
+                    cacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], xr[b][4 * q + 2], cacc, 0, 0, 0);
+                    cacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], xr[b][4 * q + 3], cacc, 0, 0, 0);
+                }
+                acc[a][b] = cacc;
+            }
+        }
+        if (ch == nchunks - 1) {  // tile finished: arg-min over its NA*NB accumulators
+#pragma unroll
+            for (int a = 0; a < NA; a++) {
+                f32x4 cnv[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                    cnv[g] = *reinterpret_cast<const f32x4*>(cur + PIECE_F + a * 32 + 8 * g + 4 * h);
+                const unsigned codebase = (unsigned)(ct * NA + a) * 16u;
+#pragma unroll
+                for (int b = 0; b < NB; b++) epilogue16(bestd[b], bestc[b], acc[a][b], xn[b], cnv, codebase);
+            }
+        }
+        if (++ch == nchunks) { ch = 0; ct++; }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        int idx = -1;
+        if (bestc[b] != 0xffffffffu) {
+            const unsigned r = bestc[b] & 15u;
+            idx = (int)((bestc[b] >> 4) * 32u + (r & 3u) + 8u * (r >> 2) + 4u * (unsigned)h);
+        }
+        const float od = __shfl_xor(bestd[b], 32);
+        const int oi = __shfl_xor(idx, 32);
+        float fd = bestd[b];
+        int fi = idx;
+        if (od < fd || (od == fd && (unsigned)oi < (unsigned)fi)) {
+            fd = od;
+            fi = oi;
+        }
+        const long r = row0 + 32 * b + j;
+        if (h == 0 && r < n) {
+            ids[r] = (long)fi;
+            if (dist) dist[r] = fd;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Any d at all (fallback: scalar fmaf chains, one thread per row; same arithmetic as the MFMA path).
+// Used only when d is not a multiple of 4 or the rows are not 16-byte aligned.
 __global__ void __launch_bounds__(WG)
 assign_generic_kernel(const float* __restrict__ X, long n, int d, const float* __restrict__ C,
                       const float* __restrict__ cn, int k, long* __restrict__ ids,
@@ -410,6 +592,25 @@ extern "C" int at_assign_f32(at_ctx* ctx, const float* x, int64_t n, int d, cons
         }
         if (v == 1) return launch_mfma<128, 1, 2, false, 2>(ctx, x, n, c, k, ids, dist, stream);
         return launch_mfma<128, 1, 2, true, 2>(ctx, x, n, c, k, ids, dist, stream);
+    }
+
+    if (d % 4 == 0 && at_aligned16(x) && assign_variant() != 2) {
+        constexpr int NB = 2, NA = 2;
+        const int nchunks = (d + DC - 1) / DC;
+        const int ntiles = (k + tile_rows(NA) - 1) / tile_rows(NA);
+        const size_t tile_f = (size_t)tile_rows(NA) * DC * nchunks + CN_PAD;
+        float* img = static_cast<float*>(at_ws(ctx, WS_CENT_IMG, sizeof(float) * ntiles * tile_f, stream));
+        if (!img) return AT_E_NOMEM;
+        hipLaunchKernelGGL(prep_centroids_chunked_kernel, dim3(ntiles), dim3(WG), 0, stream, c, k, d, nchunks,
+                           NA, img);
+        AT_LAUNCH_CHECK();
+        const size_t lds = 2 * sizeof(float) * (tile_rows(NA) * DC + CN_PAD);
+        const int64_t rows_per_wg = 4 * 32 * NB;
+        hipLaunchKernelGGL((assign_mfma_anyd_kernel<NB, NA>), dim3((unsigned)((n + rows_per_wg - 1) / rows_per_wg)),
+                           dim3(WG), lds, stream, x, (long)n, d, nchunks, img, ntiles,
+                           reinterpret_cast<long*>(ids), dist);
+        AT_LAUNCH_CHECK();
+        return AT_OK;
     }
 
     float* cn = static_cast<float*>(at_ws(ctx, WS_CENT_IMG, sizeof(float) * (size_t)k, stream));

@@ -56,7 +56,7 @@ def test_assign_small_batch_form(be, oracle, n):
     assert np.array_equal(bits(dis.cpu().numpy()), bits(dis_o))
 
 
-@pytest.mark.parametrize("d,k", [(8, 20), (40, 33), (80, 500), (640, 64)])
+@pytest.mark.parametrize("d,k", [(8, 20), (40, 33), (80, 500), (640, 64), (192, 700), (50, 77), (6, 9), (1280, 40)])
 def test_assign_generic_d(be, oracle, d, k):
     rng = np.random.default_rng(d + k)
     x = _unit_rows(rng, 1500, d, oracle)

@@ -6,7 +6,7 @@ import torch
 from audio_tokens_amd.backend import default_backend
 be = default_backend()
 variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,1,2,3,4".split(","))]
-shapes = [(2097152, 64, 8192), (2097152, 128, 8192)]
+shapes = [(2097152, 64, 8192), (2097152, 128, 8192)] if len(sys.argv) < 3 else [tuple(int(v) for v in a.split("x")) for a in sys.argv[2:]]
 g = torch.Generator(device="cuda").manual_seed(0)
 for (n, d, k) in shapes:
     x = torch.nn.functional.normalize(torch.randn(n, d, device="cuda", generator=g), dim=1)
