@@ -107,6 +107,34 @@ __device__ __forceinline__ void epilogue16(float& bestd, unsigned& bestc, const 
     bestc = br != 16u ? (codebase | br) : bestc;
 }
 
+// Speculative form: the 16 unclamped distances and their minimum cost 2.5 VALU per element; the
+// exact 4-op update (clamp, compare, two selects) runs only when some lane of the wave improves
+// (a clamped distance can beat bestd only if the unclamped one does, since bestd >= 0).
+template <int R>
+__device__ __forceinline__ void update_from(float& bd, unsigned& br, const float (&dis)[16]) {
+    if constexpr (R < 16) {
+        argmin_step<R>(bd, br, __builtin_fmaxf(dis[R], 0.0f));
+        update_from<R + 1>(bd, br, dis);
+    }
+}
+
+__device__ __forceinline__ void epilogue16_spec(float& bestd, unsigned& bestc, const f32x16& acc, float xn,
+                                                const f32x4 (&cnv)[4], unsigned codebase) {
+    float dis[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) dis[r] = __builtin_fmaf(-2.0f, acc[r], xn + cnv[r >> 2][r & 3]);
+    float m = __builtin_fminf(dis[0], dis[1]);
+#pragma unroll
+    for (int r = 2; r < 16; r += 2) m = __builtin_fminf(__builtin_fminf(m, dis[r]), dis[r + 1]);
+    if (__builtin_amdgcn_ballot_w64(m < bestd) != 0) {
+        float bd = bestd;
+        unsigned br = 16u;
+        update_from<0>(bd, br, dis);
+        bestd = bd;
+        bestc = br != 16u ? (codebase | br) : bestc;
+    }
+}
+
 // 1 KiB of global memory -> LDS without passing through registers (global_load_lds_dwordx4):
 // lane l's 16 bytes land at lds_wave_base + 16*l.
 __device__ __forceinline__ void dma_1k(const float* gsrc_lane, float* lds_wave_base) {
@@ -116,7 +144,7 @@ __device__ __forceinline__ void dma_1k(const float* gsrc_lane, float* lds_wave_b
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int D, int NB, int NA, bool DMA, int WAVES_PER_SIMD>
+template <int D, int NB, int NA, bool DMA, int WAVES_PER_SIMD, bool SPEC = false>
 __global__ void __launch_bounds__(WG, WAVES_PER_SIMD)
 assign_mfma_kernel(const float* __restrict__ X, long n, const float* __restrict__ img, int ntiles,
                    long* __restrict__ ids, float* __restrict__ dist) {
@@ -236,6 +264,10 @@ assign_mfma_kernel(const float* __restrict__ X, long n, const float* __restrict_
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], xr[b][4 * q + 1], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], xr[b][4 * q + 2], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], xr[b][4 * q + 3], acc, 0, 0, 0);
+                }
+                if constexpr (SPEC) {
+                    epilogue16_spec(bestd[b], bestc[b], acc, xn[b], cnv, codebase);
+                    continue;
                 }
                 if (a == 0 && b == 0)  // previous tile's last accumulator (no-op on the first tile)
                     epilogue16(bestd[NB - 1], bestc[NB - 1], accP, xn[NB - 1], cnP, codeP);
@@ -531,7 +563,7 @@ __global__ void assign_small_kernel(const float* __restrict__ X, int n, int d,
     if (dist) dist[i] = best;
 }
 
-template <int D, int NB, int NA, bool DMA, int WPS>
+template <int D, int NB, int NA, bool DMA, int WPS, bool SPEC = false>
 int launch_mfma(at_ctx* ctx, const float* x, int64_t n, const float* c, int k, int64_t* ids, float* dist,
                 hipStream_t stream) {
     const int ntiles = (k + tile_rows(NA) - 1) / tile_rows(NA);
@@ -546,11 +578,11 @@ int launch_mfma(at_ctx* ctx, const float* x, int64_t n, const float* c, int k, i
     static bool attr_set = false;
     if (!attr_set) {
         AT_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&assign_mfma_kernel<D, NB, NA, DMA, WPS>),
+            reinterpret_cast<const void*>(&assign_mfma_kernel<D, NB, NA, DMA, WPS, SPEC>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((assign_mfma_kernel<D, NB, NA, DMA, WPS>), dim3((unsigned)grid), dim3(WG), lds,
+    hipLaunchKernelGGL((assign_mfma_kernel<D, NB, NA, DMA, WPS, SPEC>), dim3((unsigned)grid), dim3(WG), lds,
                        stream, x, (long)n, img, ntiles, reinterpret_cast<long*>(ids), dist);
     AT_LAUNCH_CHECK();
     return AT_OK;
@@ -588,9 +620,11 @@ extern "C" int at_assign_f32(at_ctx* ctx, const float* x, int64_t n, int d, cons
         const int v = assign_variant();
         if (d == 64) {
             if (v == 1) return launch_mfma<64, 2, 2, false, 2>(ctx, x, n, c, k, ids, dist, stream);
+            if (v == 3) return launch_mfma<64, 2, 4, true, 2, true>(ctx, x, n, c, k, ids, dist, stream);
             return launch_mfma<64, 2, 4, true, 2>(ctx, x, n, c, k, ids, dist, stream);
         }
         if (v == 1) return launch_mfma<128, 1, 2, false, 2>(ctx, x, n, c, k, ids, dist, stream);
+        if (v == 3) return launch_mfma<128, 1, 2, true, 2, true>(ctx, x, n, c, k, ids, dist, stream);
         return launch_mfma<128, 1, 2, true, 2>(ctx, x, n, c, k, ids, dist, stream);
     }
 

@@ -154,7 +154,7 @@ def main():
     roofline = {
         "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-        "kernel": "assign_mfma_kernel<64,2> (at_assign_f32)", "launches": len(trace),
+        "kernel": "assign_mfma_kernel<64,2,4,DMA,2> (at_assign_f32)", "launches": len(trace),
         "avg_launch_ms": ms / max(1, len(trace)), "flop_per_launch": flops / max(1, len(trace)),
         "share_of_step_time": (ms * 1e-3) / elapsed if elapsed > 0 else None,
     }
