@@ -169,6 +169,30 @@ class HipBackend(HostHelpers):
             rec.append((n, d, k, e0, e1))
         return ids, dist
 
+    def assign_hinted(self, x, c, hint_ids, order=None, want_dist=True):
+        """Same result as assign(), faster when hint_ids (int64 [n], previous assignment) are mostly
+        right; `order` (uint32 as int32 tensor [n], from centroid_accum(..., want_order=True)) groups
+        equal hints."""
+        x, c = self._f32(x), self._f32(c)
+        n, d = x.shape
+        k = c.shape[0]
+        assert hint_ids.dtype == torch.int64 and hint_ids.is_contiguous() and hint_ids.numel() == n
+        if order is not None:
+            assert order.dtype == torch.int32 and order.is_contiguous() and order.numel() == n
+        ids = self.empty((n,), torch.int64)
+        dist = self.empty((n,), torch.float32) if want_dist else None
+        rec = self.assign_trace
+        if rec is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_assign_hinted_f32(self.ctx.handle, _ptr(x), n, d, _ptr(c), k, _ptr(hint_ids),
+                                                     _ptr(order), _ptr(ids), _ptr(dist), self._stream()))
+        if rec is not None:
+            e1.record(torch.cuda.current_stream(self.device))
+            rec.append((n, d, k, e0, e1))
+        return ids, dist
+
     def gather_rows(self, x, idx) -> torch.Tensor:
         x = self._f32(x)
         if isinstance(idx, np.ndarray):
@@ -181,18 +205,20 @@ class HipBackend(HostHelpers):
                                                    self._stream()))
         return out
 
-    def centroid_accum(self, x, ids, k, out=None) -> torch.Tensor:
-        """Packed partial result [k*d + k]: sums [k, d] followed by counts [k]."""
+    def centroid_accum(self, x, ids, k, out=None, want_order=False):
+        """Packed partial result [k*d + k]: sums [k, d] followed by counts [k].  With want_order also
+        the rows sorted by (id, row) as an int32 tensor (uint32 bit pattern) for assign_hinted."""
         x = self._f32(x)
         n, d = x.shape
         assert ids.dtype == torch.int64 and ids.is_contiguous() and ids.numel() == n
         if out is None:
             out = self.empty((k * d + k,))
+        order = self.empty((n,), torch.int32) if want_order else None
         with torch.cuda.device(self.device):
             _lib.check(self.lib.at_centroid_accum_f32(
                 self.ctx.handle, _ptr(x), n, d, _ptr(ids), k, _ptr(out), _vp(out.data_ptr() + 4 * k * d),
-                self._stream()))
-        return out
+                _ptr(order), self._stream()))
+        return (out, order) if want_order else out
 
     def centroid_finalize(self, parts, k, d):
         """parts [n_parts, k*d + k] packed partials (rank order) -> (centroids [k, d], hassign [k])."""

@@ -321,6 +321,159 @@ assign_mfma_kernel(const float* __restrict__ X, long n, const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// Hinted sweep (Lloyd iterations after the first).  Every row arrives with a guess -- its
+// assignment in the previous iteration -- and rows are visited in an order that groups equal
+// guesses (the member-list order the centroid update has just built).  The guess's distance is
+// evaluated exactly up front (the same ascending fmaf chain, on the VALU) and becomes the running
+// best, so during the sweep an accumulator can matter only if its minimum reaches that best:
+// per accumulator the wave computes 16 unclamped distances and their minimum (2.5 VALU per
+// element instead of 6) and enters the exact update -- lexicographic (distance, index), so that the
+// answer is the brute-force arg-min with lowest-index ties whatever the guess was -- only when some
+// lane needs it.  With grouped guesses that is the guess's own tile plus the rows that really move.
+template <int D, int NB, int NA>
+__global__ void __launch_bounds__(WG, 2)
+assign_mfma_hinted_kernel(const float* __restrict__ X, long n, const float* __restrict__ C, int k,
+                          const float* __restrict__ img, int ntiles, const uint32_t* __restrict__ order,
+                          const long* __restrict__ hint, long* __restrict__ ids,
+                          float* __restrict__ dist) {
+    constexpr int R = tile_rows(NA);
+    constexpr int TILE_F = tile_floats(D, NA);
+    constexpr int PIECES = TILE_F / 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 * TILE_F floats
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31;
+    const int h = lane >> 5;
+    const long pos0 = ((long)blockIdx.x * 4 + wave) * (32 * NB);
+
+    float xr[NB][D / 2];
+    float xn[NB];
+    float bestd[NB];
+    unsigned besti[NB];
+    long rowid[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        long pos = pos0 + 32 * b + j;
+        if (pos >= n) pos = n - 1;
+        const long r = order ? (long)order[pos] : pos;
+        rowid[b] = r;
+        const f32x4* p = reinterpret_cast<const f32x4*>(X + r * D);
+        const long g = hint ? hint[r] : -1;
+        const bool has = g >= 0 && g < k;
+        const f32x4* pc = reinterpret_cast<const f32x4*>(C + (has ? g : 0) * D);
+        float nrm = 0.0f, cnn = 0.0f, ip = 0.0f;
+        // exact distance to the guess: three ascending fmaf chains (rolled loop: keeps the register
+        // footprint of this one-off prologue small)
+#pragma clang loop unroll(disable)
+        for (int q = 0; q < D / 4; q++) {
+            const f32x4 u = p[q], cu = pc[q];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                nrm = __builtin_fmaf(u[e], u[e], nrm);
+                cnn = __builtin_fmaf(cu[e], cu[e], cnn);
+                ip = __builtin_fmaf(cu[e], u[e], ip);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < D / 8; q++) {
+            const f32x4 u = p[2 * q], v = p[2 * q + 1];
+            xr[b][4 * q + 0] = h ? u[1] : u[0];
+            xr[b][4 * q + 1] = h ? u[3] : u[2];
+            xr[b][4 * q + 2] = h ? v[1] : v[0];
+            xr[b][4 * q + 3] = h ? v[3] : v[2];
+        }
+        xn[b] = nrm;
+        const float dh = __builtin_fmaxf(__builtin_fmaf(-2.0f, ip, nrm + cnn), 0.0f);
+        bestd[b] = has ? dh : __builtin_inff();
+        besti[b] = has ? (unsigned)g : 0xffffffffu;
+    }
+
+    auto stage_dma = [&](int tile, float* dst) {
+        const float* src = img + (size_t)tile * TILE_F;
+#pragma unroll
+        for (int p0 = 0; p0 < PIECES; p0 += 4) {
+            const int p = p0 + wave;
+            if (p < PIECES) dma_1k(src + p * 256 + lane * 4, dst + p * 256);
+        }
+    };
+    stage_dma(0, smem);
+    __syncthreads();
+
+    const int swz = j & 15;
+    for (int ct = 0; ct < ntiles; ct++) {
+        const float* cur = smem + (ct & 1) * TILE_F;
+        if (ct + 1 < ntiles) stage_dma(ct + 1, smem + ((ct + 1) & 1) * TILE_F);
+#pragma unroll
+        for (int a = 0; a < NA; a++) {
+            f32x4 cnv[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                cnv[g] = *reinterpret_cast<const f32x4*>(cur + R * D + a * 32 + 8 * g + 4 * h);
+            const float* arow = cur + (a * 32 + j) * D;
+            const unsigned jobbase = (unsigned)(ct * NA + a) * 32u + 4u * (unsigned)h;
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < D / 8; q++) {
+                    const int pcx = (2 * q + h) ^ swz;
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(arow + pcx * 4);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], xr[b][4 * q + 0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], xr[b][4 * q + 1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], xr[b][4 * q + 2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], xr[b][4 * q + 3], acc, 0, 0, 0);
+                }
+                // minimum of the 16 unclamped distances (nothing kept: the rare exact update below
+                // recomputes them from the accumulator)
+                float m = __builtin_inff();
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float d0 = __builtin_fmaf(-2.0f, acc[r], xn[b] + cnv[r >> 2][r & 3]);
+                    const float d1 = __builtin_fmaf(-2.0f, acc[r + 1], xn[b] + cnv[(r + 1) >> 2][(r + 1) & 3]);
+                    m = __builtin_fminf(__builtin_fminf(m, d0), d1);
+                }
+                // a clamped distance can tie or beat bestd (>= 0) only if the unclamped one does
+                if (__builtin_amdgcn_ballot_w64(m <= bestd[b]) != 0) {
+                    float bd = bestd[b];
+                    unsigned bi = besti[b];
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const float dd = __builtin_fmaxf(
+                            __builtin_fmaf(-2.0f, acc[r], xn[b] + cnv[r >> 2][r & 3]), 0.0f);
+                        const unsigned idx = jobbase + (unsigned)((r & 3) + 8 * (r >> 2));
+                        const bool better = dd < bd || (dd == bd && idx < bi);
+                        bd = better ? dd : bd;
+                        bi = better ? idx : bi;
+                    }
+                    bestd[b] = bd;
+                    besti[b] = bi;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const float od = __shfl_xor(bestd[b], 32);
+        const unsigned oi = (unsigned)__shfl_xor((int)besti[b], 32);
+        float fd = bestd[b];
+        unsigned fi = besti[b];
+        if (od < fd || (od == fd && oi < fi)) {
+            fd = od;
+            fi = oi;
+        }
+        const long pos = pos0 + 32 * b + j;
+        if (h == 0 && pos < n) {
+            ids[rowid[b]] = fi == 0xffffffffu ? -1L : (long)fi;
+            if (dist) dist[rowid[b]] = fd;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Any d that is a multiple of 4 (n_mels other than 64/128, use_convolution's d = 10*n_mels):
 // the same MFMA sweep with the feature axis cut into chunks of 64.  The NA*NB accumulators of a
 // centroid tile stay live across the chunks (so every inner product is still ONE ascending fmaf
@@ -653,6 +806,60 @@ extern "C" int at_assign_f32(at_ctx* ctx, const float* x, int64_t n, int d, cons
     AT_LAUNCH_CHECK();
     hipLaunchKernelGGL(assign_generic_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0,
                        stream, x, (long)n, d, c, cn, k, reinterpret_cast<long*>(ids), dist);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}
+
+extern "C" int at_assign_hinted_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
+                                    const int64_t* hint_ids, const uint32_t* order, int64_t* ids,
+                                    float* dist, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AT_REQUIRE(ctx, "at_assign_hinted_f32: ctx is null");
+    // shapes without a hinted kernel, or no hints at all: the plain sweep gives the same answer
+    if (!hint_ids || n < 20 || !(d == 64 || d == 128) || !at_aligned16(x) || !at_aligned16(c))
+        return at_assign_f32(ctx, x, n, d, c, k, ids, dist, stream_);
+    AT_REQUIRE(n >= 0 && k > 0 && k <= (1 << 24) && n < (int64_t)UINT32_MAX, "at_assign_hinted_f32: bad sizes");
+    AT_REQUIRE(x && c && ids, "at_assign_hinted_f32: null pointer");
+    AT_REQUIRE(ids != hint_ids, "at_assign_hinted_f32: ids must not alias hint_ids");
+    AT_HIP(hipSetDevice(ctx->device));
+    if (d == 64) {
+        constexpr int D = 64, NB = 2, NA = 4;
+        const int ntiles = (k + tile_rows(NA) - 1) / tile_rows(NA);
+        float* img = static_cast<float*>(at_ws(ctx, WS_CENT_IMG, sizeof(float) * (size_t)ntiles * tile_floats(D, NA), stream));
+        if (!img) return AT_E_NOMEM;
+        hipLaunchKernelGGL(prep_centroids_kernel, dim3(ntiles), dim3(WG), 0, stream, c, k, D, D, NA, img);
+        AT_LAUNCH_CHECK();
+        const size_t lds = 2 * sizeof(float) * tile_floats(D, NA);
+        static bool attr_set = false;
+        if (!attr_set) {
+            AT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&assign_mfma_hinted_kernel<D, NB, NA>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        const int64_t rows_per_wg = 4 * 32 * NB;
+        hipLaunchKernelGGL((assign_mfma_hinted_kernel<D, NB, NA>), dim3((unsigned)((n + rows_per_wg - 1) / rows_per_wg)),
+                           dim3(WG), lds, stream, x, (long)n, c, k, img, ntiles, order,
+                           reinterpret_cast<const long*>(hint_ids), reinterpret_cast<long*>(ids), dist);
+        AT_LAUNCH_CHECK();
+        return AT_OK;
+    }
+    constexpr int D = 128, NB = 1, NA = 2;
+    const int ntiles = (k + tile_rows(NA) - 1) / tile_rows(NA);
+    float* img = static_cast<float*>(at_ws(ctx, WS_CENT_IMG, sizeof(float) * (size_t)ntiles * tile_floats(D, NA), stream));
+    if (!img) return AT_E_NOMEM;
+    hipLaunchKernelGGL(prep_centroids_kernel, dim3(ntiles), dim3(WG), 0, stream, c, k, D, D, NA, img);
+    AT_LAUNCH_CHECK();
+    const size_t lds = 2 * sizeof(float) * tile_floats(D, NA);
+    static bool attr_set128 = false;
+    if (!attr_set128) {
+        AT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&assign_mfma_hinted_kernel<D, NB, NA>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set128 = true;
+    }
+    const int64_t rows_per_wg = 4 * 32 * NB;
+    hipLaunchKernelGGL((assign_mfma_hinted_kernel<D, NB, NA>), dim3((unsigned)((n + rows_per_wg - 1) / rows_per_wg)),
+                       dim3(WG), lds, stream, x, (long)n, c, k, img, ntiles, order,
+                       reinterpret_cast<const long*>(hint_ids), reinterpret_cast<long*>(ids), dist);
     AT_LAUNCH_CHECK();
     return AT_OK;
 }

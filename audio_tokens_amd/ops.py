@@ -264,13 +264,17 @@ class Kmeans:
             prof[name] = prof.get(name, 0.0) + (now - t_prev)
             return now
 
+        ids = order = None
         for it in range(self.niter):
             ts = time.time()
             tp = time.perf_counter()
-            ids, dis = be.assign(xs, cent)
+            if ids is None:
+                ids, dis = be.assign(xs, cent)
+            else:  # same answer, guided by the previous assignment and its member-list order
+                ids, dis = be.assign_hinted(xs, cent, ids, order)
             tp = lap("assign", tp)
             obj = dist.sum_f64(be.sum_f64(dis))
-            part = be.centroid_accum(xs, ids, k)
+            part, order = be.centroid_accum(xs, ids, k, want_order=True)
             tp = lap("accumulate", tp)
             parts = dist.all_gather_parts(part)
             cent, hassign = be.centroid_finalize(parts, k, d)

@@ -48,18 +48,22 @@ class OracleBackend(HostHelpers):
         ids, dis = oracle.assign(self._f32(x).numpy(), self._f32(c).numpy())
         return torch.from_numpy(ids), (torch.from_numpy(dis) if want_dist else None)
 
+    def assign_hinted(self, x, c, hint_ids, order=None, want_dist=True):
+        return self.assign(x, c, want_dist)          # hints never change the answer
+
     def gather_rows(self, x, idx):
         idx = idx if isinstance(idx, np.ndarray) else idx.numpy()
         return self._f32(x)[torch.from_numpy(idx.astype(np.int64))].contiguous()
 
-    def centroid_accum(self, x, ids, k, out=None):
+    def centroid_accum(self, x, ids, k, out=None, want_order=False):
         x = self._f32(x).numpy()
         d = x.shape[1]
         sums = np.zeros((k, d), np.float32)
         counts = np.zeros(k, np.float32)
         np.add.at(sums, ids.numpy(), x)          # unbuffered, ascending i: the sequential fp32 sum
         np.add.at(counts, ids.numpy(), np.float32(1))
-        return torch.from_numpy(np.concatenate([sums.ravel(), counts]))
+        part = torch.from_numpy(np.concatenate([sums.ravel(), counts]))
+        return (part, None) if want_order else part
 
     def centroid_finalize(self, parts, k, d):
         parts = parts.reshape(-1, k * d + k).numpy()

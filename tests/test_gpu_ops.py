@@ -45,6 +45,35 @@ def test_assign_unnormalised_and_ties(be, oracle):
     assert (ids_o[100:150] < 200).all()
 
 
+@pytest.mark.parametrize("n,d,k", [(5000, 64, 300), (70000, 64, 8192), (3000, 128, 1000), (40000, 128, 4096)])
+def test_assign_hinted_is_hint_independent(be, oracle, n, d, k):
+    """at_assign_hinted_f32 must return the brute-force answer whatever it is told."""
+    rng = np.random.default_rng(n + d + k)
+    x = _unit_rows(rng, n, d, oracle)
+    c = _unit_rows(rng, k, d, oracle)
+    c[k // 2: k // 2 + 20] = c[0:20]                 # duplicate centroids: lowest index must win
+    x[:20] = c[k // 2: k // 2 + 20]                  # rows sitting on them (clamped distance 0)
+    ids_o, dis_o = oracle.assign(x, c)
+    xt, ct = be._f32(x), be._f32(c)
+    truth = torch.from_numpy(ids_o).to(be.device)
+    hints = {
+        "truth": truth,
+        "random": torch.from_numpy(rng.integers(0, k, n)).to(be.device),
+        "none": torch.full((n,), -1, dtype=torch.int64, device=be.device),
+        "dup_high": torch.where(truth < 20, truth + k // 2, truth),   # the higher-index twin of the winner
+        "mixed": torch.where(torch.arange(n, device=be.device) % 3 == 0, truth, (truth + 7) % k),
+    }
+    for name, hint in hints.items():
+        part, order = be.centroid_accum(xt, torch.clamp(hint, min=0), k, want_order=True)
+        for od in (None, order):
+            ids, dis = be.assign_hinted(xt, ct, hint.contiguous(), od)
+            assert np.array_equal(ids.cpu().numpy(), ids_o), f"hint={name} order={'yes' if od is not None else 'no'}"
+            assert np.array_equal(bits(dis.cpu().numpy()), bits(dis_o)), name
+    # the order returned by centroid_accum is the stable sort by (id, row)
+    part, order = be.centroid_accum(xt, truth, k, want_order=True)
+    assert np.array_equal(order.cpu().numpy().view(np.uint32), np.argsort(ids_o, kind="stable").astype(np.uint32))
+
+
 @pytest.mark.parametrize("n", [1, 5, 19])
 def test_assign_small_batch_form(be, oracle, n):
     rng = np.random.default_rng(n)
