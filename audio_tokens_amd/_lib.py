@@ -33,9 +33,9 @@ SIGNATURES = {
     "at_logmel_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),
     "at_l2norm_rows_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "at_assign_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp]),
-    "at_assign_hinted_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "at_assign_hinted_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "at_gather_rows_f32": (_i32, [_vp, _vp, _i32, _vp, _i64, _vp, _vp]),
-    "at_centroid_accum_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "at_centroid_accum_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "at_centroid_finalize_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "at_sum_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "at_any_nonfinite_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),

@@ -76,7 +76,7 @@ class HipBackend(HostHelpers):
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = device
         self.ctx = _lib.context(device.index)
-        self.assign_trace = None  # set to a list to collect (n, d, k, start_event, end_event)
+        self.assign_trace = None  # set to a list to collect (kind, n, d, k, start_event, end_event)
 
     # -- plumbing --------------------------------------------------------------------------
     def _stream(self) -> _vp:
@@ -166,19 +166,23 @@ class HipBackend(HostHelpers):
                                               _ptr(dist), self._stream()))
         if rec is not None:
             e1.record(torch.cuda.current_stream(self.device))
-            rec.append((n, d, k, e0, e1))
+            rec.append(("plain", n, d, k, e0, e1))
         return ids, dist
 
     def assign_hinted(self, x, c, hint_ids, order=None, want_dist=True):
-        """Same result as assign(), faster when hint_ids (int64 [n], previous assignment) are mostly
-        right; `order` (uint32 as int32 tensor [n], from centroid_accum(..., want_order=True)) groups
-        equal hints."""
+        """Same result as assign(), faster when the hints (the previous assignment) are mostly right.
+        hint_ids: int64 [n] per row.  order: what centroid_accum(..., want_order=True) returned for
+        those ids -- a pair (rows in member-list order, their ids in that order), both uint32 bit
+        patterns in int32 tensors -- or None."""
         x, c = self._f32(x), self._f32(c)
         n, d = x.shape
         k = c.shape[0]
         assert hint_ids.dtype == torch.int64 and hint_ids.is_contiguous() and hint_ids.numel() == n
+        hint_sorted = None
         if order is not None:
-            assert order.dtype == torch.int32 and order.is_contiguous() and order.numel() == n
+            order, hint_sorted = order
+            for t in (order, hint_sorted):
+                assert t.dtype == torch.int32 and t.is_contiguous() and t.numel() == n
         ids = self.empty((n,), torch.int64)
         dist = self.empty((n,), torch.float32) if want_dist else None
         rec = self.assign_trace
@@ -187,10 +191,11 @@ class HipBackend(HostHelpers):
             e0.record(torch.cuda.current_stream(self.device))
         with torch.cuda.device(self.device):
             _lib.check(self.lib.at_assign_hinted_f32(self.ctx.handle, _ptr(x), n, d, _ptr(c), k, _ptr(hint_ids),
-                                                     _ptr(order), _ptr(ids), _ptr(dist), self._stream()))
+                                                     _ptr(order), _ptr(hint_sorted), _ptr(ids), _ptr(dist),
+                                                     self._stream()))
         if rec is not None:
             e1.record(torch.cuda.current_stream(self.device))
-            rec.append((n, d, k, e0, e1))
+            rec.append(("hinted", n, d, k, e0, e1))
         return ids, dist
 
     def gather_rows(self, x, idx) -> torch.Tensor:
@@ -207,18 +212,20 @@ class HipBackend(HostHelpers):
 
     def centroid_accum(self, x, ids, k, out=None, want_order=False):
         """Packed partial result [k*d + k]: sums [k, d] followed by counts [k].  With want_order also
-        the rows sorted by (id, row) as an int32 tensor (uint32 bit pattern) for assign_hinted."""
+        (rows sorted by (id, row), their ids in that order) as int32 tensors holding uint32 bit
+        patterns -- the `order` argument of assign_hinted."""
         x = self._f32(x)
         n, d = x.shape
         assert ids.dtype == torch.int64 and ids.is_contiguous() and ids.numel() == n
         if out is None:
             out = self.empty((k * d + k,))
         order = self.empty((n,), torch.int32) if want_order else None
+        sorted_ids = self.empty((n,), torch.int32) if want_order else None
         with torch.cuda.device(self.device):
             _lib.check(self.lib.at_centroid_accum_f32(
                 self.ctx.handle, _ptr(x), n, d, _ptr(ids), k, _ptr(out), _vp(out.data_ptr() + 4 * k * d),
-                _ptr(order), self._stream()))
-        return (out, order) if want_order else out
+                _ptr(order), _ptr(sorted_ids), self._stream()))
+        return (out, (order, sorted_ids)) if want_order else out
 
     def centroid_finalize(self, parts, k, d):
         """parts [n_parts, k*d + k] packed partials (rank order) -> (centroids [k, d], hassign [k])."""

@@ -334,8 +334,8 @@ template <int D, int NB, int NA>
 __global__ void __launch_bounds__(WG, 2)
 assign_mfma_hinted_kernel(const float* __restrict__ X, long n, const float* __restrict__ C, int k,
                           const float* __restrict__ img, int ntiles, const uint32_t* __restrict__ order,
-                          const long* __restrict__ hint, long* __restrict__ ids,
-                          float* __restrict__ dist) {
+                          const long* __restrict__ hint, const uint32_t* __restrict__ hint_sorted,
+                          long* __restrict__ ids, float* __restrict__ dist) {
     constexpr int R = tile_rows(NA);
     constexpr int TILE_F = tile_floats(D, NA);
     constexpr int PIECES = TILE_F / 256;
@@ -360,7 +360,8 @@ assign_mfma_hinted_kernel(const float* __restrict__ X, long n, const float* __re
         const long r = order ? (long)order[pos] : pos;
         rowid[b] = r;
         const f32x4* p = reinterpret_cast<const f32x4*>(X + r * D);
-        const long g = hint ? hint[r] : -1;
+        // guesses listed in visiting order are one coalesced read; per-row guesses are a gather
+        const long g = hint_sorted ? (long)hint_sorted[pos] : (hint ? hint[r] : -1);
         const bool has = g >= 0 && g < k;
         const f32x4* pc = reinterpret_cast<const f32x4*>(C + (has ? g : 0) * D);
         float nrm = 0.0f, cnn = 0.0f, ip = 0.0f;
@@ -811,12 +812,13 @@ extern "C" int at_assign_f32(at_ctx* ctx, const float* x, int64_t n, int d, cons
 }
 
 extern "C" int at_assign_hinted_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
-                                    const int64_t* hint_ids, const uint32_t* order, int64_t* ids,
-                                    float* dist, void* stream_) {
+                                    const int64_t* hint_ids, const uint32_t* order,
+                                    const uint32_t* hint_sorted, int64_t* ids, float* dist, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     AT_REQUIRE(ctx, "at_assign_hinted_f32: ctx is null");
     // shapes without a hinted kernel, or no hints at all: the plain sweep gives the same answer
-    if (!hint_ids || n < 20 || !(d == 64 || d == 128) || !at_aligned16(x) || !at_aligned16(c))
+    if (hint_sorted && !order) hint_sorted = nullptr;  // positions mean nothing without the order
+    if ((!hint_ids && !hint_sorted) || n < 20 || !(d == 64 || d == 128) || !at_aligned16(x) || !at_aligned16(c))
         return at_assign_f32(ctx, x, n, d, c, k, ids, dist, stream_);
     AT_REQUIRE(n >= 0 && k > 0 && k <= (1 << 24) && n < (int64_t)UINT32_MAX, "at_assign_hinted_f32: bad sizes");
     AT_REQUIRE(x && c && ids, "at_assign_hinted_f32: null pointer");
@@ -839,7 +841,7 @@ extern "C" int at_assign_hinted_f32(at_ctx* ctx, const float* x, int64_t n, int 
         const int64_t rows_per_wg = 4 * 32 * NB;
         hipLaunchKernelGGL((assign_mfma_hinted_kernel<D, NB, NA>), dim3((unsigned)((n + rows_per_wg - 1) / rows_per_wg)),
                            dim3(WG), lds, stream, x, (long)n, c, k, img, ntiles, order,
-                           reinterpret_cast<const long*>(hint_ids), reinterpret_cast<long*>(ids), dist);
+                           reinterpret_cast<const long*>(hint_ids), hint_sorted, reinterpret_cast<long*>(ids), dist);
         AT_LAUNCH_CHECK();
         return AT_OK;
     }
@@ -859,7 +861,7 @@ extern "C" int at_assign_hinted_f32(at_ctx* ctx, const float* x, int64_t n, int 
     const int64_t rows_per_wg = 4 * 32 * NB;
     hipLaunchKernelGGL((assign_mfma_hinted_kernel<D, NB, NA>), dim3((unsigned)((n + rows_per_wg - 1) / rows_per_wg)),
                        dim3(WG), lds, stream, x, (long)n, c, k, img, ntiles, order,
-                       reinterpret_cast<const long*>(hint_ids), reinterpret_cast<long*>(ids), dist);
+                       reinterpret_cast<const long*>(hint_ids), hint_sorted, reinterpret_cast<long*>(ids), dist);
     AT_LAUNCH_CHECK();
     return AT_OK;
 }

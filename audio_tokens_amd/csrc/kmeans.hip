@@ -299,7 +299,8 @@ int at_gather_rows_f32(at_ctx* ctx, const float* x, int d, const int32_t* idx, i
 }
 
 int at_centroid_accum_f32(at_ctx* ctx, const float* x, int64_t n, int d, const int64_t* ids, int k,
-                          float* sums, float* counts, uint32_t* order_out, void* stream_) {
+                          float* sums, float* counts, uint32_t* order_out, uint32_t* sorted_ids_out,
+                          void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     AT_REQUIRE(ctx, "at_centroid_accum_f32: ctx is null");
     AT_REQUIRE(n >= 0 && n < (int64_t)UINT32_MAX && d > 0 && k > 0 && k < (1 << 30),
@@ -359,6 +360,9 @@ int at_centroid_accum_f32(at_ctx* ctx, const float* x, int64_t n, int d, const i
     AT_LAUNCH_CHECK();
     if (order_out && n > 0)
         AT_HIP(hipMemcpyAsync(order_out, order, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+    if (sorted_ids_out && n > 0)
+        AT_HIP(hipMemcpyAsync(sorted_ids_out, sorted_keys, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice,
+                              stream));
     if (long_ok && n > (int64_t)long_list) {
         // (workgroups of short clusters exit at once; gridDim.y = feature slices)
         hipLaunchKernelGGL(centroid_accum_long_kernel, dim3(k, d / 4), dim3(WG), 0, stream, x, d, order,

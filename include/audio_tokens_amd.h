@@ -105,13 +105,16 @@ int at_assign_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float* c,
                   int64_t* ids, float* dist_or_null, void* stream);
 
 /* The same answer as at_assign_f32, bit for bit, computed faster when most rows come with a correct
- * guess (a Lloyd iteration guessing the previous assignment).  hint_ids: int64 [n], guesses in
- * [0, k) or anything else for "none"; order_or_null: uint32 [n], a permutation of the rows that
- * groups equal guesses (the order_out of at_centroid_accum_f32 for those ids), or NULL.  ids must
- * not alias hint_ids.  Results do not depend on the hints or the order. */
+ * guess (a Lloyd iteration guessing the previous assignment).  Guesses are values in [0, k), or
+ * anything else for "none", given either per row (hint_ids: int64 [n]) or per visiting position
+ * (hint_sorted: uint32 [n], the guess of row order[p] at position p; needs order).  order_or_null:
+ * uint32 [n], a permutation of the rows that groups equal guesses.  at_centroid_accum_f32 produces
+ * both arrays for the ids it was given (order_out, sorted_ids_out).  ids must not alias hint_ids.
+ * Results do not depend on the hints or the order. */
 int at_assign_hinted_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
-                         const int64_t* hint_ids, const uint32_t* order_or_null, int64_t* ids,
-                         float* dist_or_null, void* stream);
+                         const int64_t* hint_ids_or_null, const uint32_t* order_or_null,
+                         const uint32_t* hint_sorted_or_null, int64_t* ids, float* dist_or_null,
+                         void* stream);
 
 /* out[i] = x[idx[i]] (rows of d floats).  idx: DEVICE int32 [m]. */
 int at_gather_rows_f32(at_ctx* ctx, const float* x, int d, const int32_t* idx, int64_t m,
@@ -120,9 +123,11 @@ int at_gather_rows_f32(at_ctx* ctx, const float* x, int d, const int32_t* idx, i
 /* faiss compute_centroids, accumulation half: sums[c] = sum of x[i] with ids[i] == c taken in
  * ASCENDING i with fp32 adds (bitwise what a single FAISS thread produces), counts[c] = number of
  * members (exact in fp32).  sums [k][d], counts [k] are overwritten.  order_out_or_null: uint32 [n],
- * receives the rows sorted by (id, row) -- the member lists, back to back. */
+ * receives the rows sorted by (id, row) -- the member lists, back to back; sorted_ids_out_or_null:
+ * uint32 [n], the id of each of those rows (k for an id outside [0, k)). */
 int at_centroid_accum_f32(at_ctx* ctx, const float* x, int64_t n, int d, const int64_t* ids, int k,
-                          float* sums, float* counts, uint32_t* order_out_or_null, void* stream);
+                          float* sums, float* counts, uint32_t* order_out_or_null,
+                          uint32_t* sorted_ids_out_or_null, void* stream);
 
 /* faiss compute_centroids, scaling half, over n_parts partial results (p = data-parallel rank):
  * part p has its sums [k][d] at sums_parts + p*sums_part_stride and its counts [k] at

@@ -70,8 +70,10 @@ def test_assign_hinted_is_hint_independent(be, oracle, n, d, k):
             assert np.array_equal(ids.cpu().numpy(), ids_o), f"hint={name} order={'yes' if od is not None else 'no'}"
             assert np.array_equal(bits(dis.cpu().numpy()), bits(dis_o)), name
     # the order returned by centroid_accum is the stable sort by (id, row)
-    part, order = be.centroid_accum(xt, truth, k, want_order=True)
-    assert np.array_equal(order.cpu().numpy().view(np.uint32), np.argsort(ids_o, kind="stable").astype(np.uint32))
+    part, (order, sorted_ids) = be.centroid_accum(xt, truth, k, want_order=True)
+    ref_order = np.argsort(ids_o, kind="stable")
+    assert np.array_equal(order.cpu().numpy().view(np.uint32), ref_order.astype(np.uint32))
+    assert np.array_equal(sorted_ids.cpu().numpy().view(np.uint32), ids_o[ref_order].astype(np.uint32))
 
 
 @pytest.mark.parametrize("n", [1, 5, 19])
