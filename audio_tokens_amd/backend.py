@@ -50,6 +50,14 @@ class HostHelpers:
     def num_frames(self, L: int, hop: int) -> int:
         return int(self.lib.at_num_frames(L, hop))
 
+    def group_rows_kd(self, rows: np.ndarray, leaf: int = 32) -> np.ndarray:
+        """Spatial grouping of a host table into groups of `leaf` rows (-1 padded permutation)."""
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        k, d = rows.shape
+        out = np.empty(((k + leaf - 1) // leaf) * leaf, np.int32)
+        _lib.check(self.lib.at_group_rows_kd_host(_np_ptr(rows), k, d, leaf, _np_ptr(out)))
+        return out
+
     def split_clusters(self, hassign: np.ndarray, centroids: np.ndarray, n: int) -> int:
         """In place on two C-contiguous float32 host arrays; returns nsplit."""
         assert hassign.dtype == np.float32 and centroids.dtype == np.float32
@@ -196,6 +204,52 @@ class HipBackend(HostHelpers):
         if rec is not None:
             e1.record(torch.cuda.current_stream(self.device))
             rec.append(("hinted", n, d, k, e0, e1))
+        return ids, dist
+
+    # -- exact pruning for Lloyd iterations ---------------------------------------------------
+    def group_min_dist(self, c, cperm) -> torch.Tensor:
+        """cperm: int32 device tensor [ng*32] (-1 padded) -> dmin float32 [k, ng]."""
+        c = self._f32(c)
+        k, d = c.shape
+        assert cperm.dtype == torch.int32 and cperm.is_contiguous() and cperm.numel() % 32 == 0
+        ng = cperm.numel() // 32
+        dmin = self.empty((k, ng))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_group_min_dist_f32(self.ctx.handle, _ptr(c), k, d, _ptr(cperm), ng, _ptr(dmin),
+                                                      self._stream()))
+        return dmin
+
+    def visit_order(self, ids, dis, k):
+        """Rows sorted by (previous id, previous distance) -> (order, ids in that order), int32
+        tensors holding uint32 bit patterns."""
+        n = ids.numel()
+        assert ids.dtype == torch.int64 and ids.is_contiguous()
+        order, hs = self.empty((n,), torch.int32), self.empty((n,), torch.int32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_visit_order_f32(self.ctx.handle, _ptr(ids), _ptr(dis), n, k, _ptr(order), _ptr(hs),
+                                                   self._stream()))
+        return order, hs
+
+    def assign_pruned(self, x, c, order, cperm, dmin, want_dist=True):
+        """Same result as assign(); `order` = visit_order(...) of the previous assignment."""
+        x, c = self._f32(x), self._f32(c)
+        n, d = x.shape
+        k = c.shape[0]
+        order, hint_sorted = order
+        ng = cperm.numel() // 32
+        ids = self.empty((n,), torch.int64)
+        dist = self.empty((n,), torch.float32) if want_dist else None
+        rec = self.assign_trace
+        if rec is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_assign_pruned_f32(self.ctx.handle, _ptr(x), n, d, _ptr(c), k, _ptr(order),
+                                                     _ptr(hint_sorted), _ptr(cperm), ng, _ptr(dmin), _ptr(ids),
+                                                     _ptr(dist), self._stream()))
+        if rec is not None:
+            e1.record(torch.cuda.current_stream(self.device))
+            rec.append(("pruned", n, d, k, e0, e1))
         return ids, dist
 
     def gather_rows(self, x, idx) -> torch.Tensor:

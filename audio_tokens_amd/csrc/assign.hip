@@ -475,6 +475,216 @@ assign_mfma_hinted_kernel(const float* __restrict__ X, long n, const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------
+// Pruned sweep (Lloyd iterations after the first; see prune.hip for the bound).  Same structure as
+// the hinted sweep, but (1) the centroid image is in spatially grouped order (a table in the tile's
+// pad maps image rows back to centroid indices for the lexicographic update), (2) every 32-row tile
+// comes with a bit mask over the 32-centroid groups: an accumulator whose bit is clear is not
+// computed at all, and a 128-centroid tile that no wave of the workgroup needs is not even staged.
+// The running best starts from the exact distance to the guess (computed by the pre-pass).
+__global__ void __launch_bounds__(WG) prep_centroids_perm_kernel(const float* __restrict__ c, int k, int d,
+                                                                 const int32_t* __restrict__ cperm, int kp,
+                                                                 int na, float* __restrict__ img) {
+    const int t = blockIdx.x;
+    const int R = tile_rows(na);
+    float* out = img + (size_t)t * tile_floats(d, na);
+    const int chunks_per_row = d / 4;
+    for (int e = threadIdx.x; e < R * chunks_per_row; e += WG) {
+        const int r = e / chunks_per_row, pc = e % chunks_per_row;
+        const int lc = pc ^ (r & 15);
+        const int q = lc >> 1, h = lc & 1;
+        const int slot = t * R + r;
+        const int row = slot < kp ? cperm[slot] : -1;
+        f32x4 v;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int f = 8 * q + 2 * u + h;
+            v[u] = (row >= 0 && f < d) ? c[(size_t)row * d + f] : 0.0f;
+        }
+        *reinterpret_cast<f32x4*>(out + (size_t)r * d + pc * 4) = v;
+    }
+    for (int r = threadIdx.x; r < 128; r += WG) {
+        const int slot = t * R + r;
+        const int row = (r < R && slot < kp) ? cperm[slot] : -1;
+        float nrm = __builtin_inff();
+        if (row >= 0) {
+            nrm = 0.0f;
+            for (int f = 0; f < d; f++) {
+                const float v = c[(size_t)row * d + f];
+                nrm = __builtin_fmaf(v, v, nrm);
+            }
+        }
+        out[R * d + r] = nrm;
+        reinterpret_cast<unsigned*>(out)[R * d + 128 + r] = row >= 0 ? (unsigned)row : 0xffffffffu;
+    }
+}
+
+// One wavefront per workgroup: a wave walks only the groups its own 32*NB rows need, staging one
+// 32-centroid group (8 or 16 KiB + norms + index table) at a time through its private double buffer.
+// No workgroup barrier anywhere: the LDS-DMA is issued and awaited (s_waitcnt vmcnt(0)) by the same
+// wave that reads it.
+constexpr int GROUP_PAD = 256;  // floats behind a group's rows: |c|^2 at [0,32), indices at [128,160)
+
+template <int D, int NB>
+__global__ void __launch_bounds__(64)
+assign_mfma_pruned_kernel(const float* __restrict__ X, long n, const float* __restrict__ img, int ng,
+                          const uint32_t* __restrict__ order, const uint32_t* __restrict__ hint_sorted,
+                          const float* __restrict__ bd_in, const uint32_t* __restrict__ mask, int ngw,
+                          long* __restrict__ ids, float* __restrict__ dist) {
+    constexpr int GROUP_F = 32 * D + GROUP_PAD;
+    constexpr int PIECES = GROUP_F / 256;
+    constexpr int MAXW = 16;  // mask words kept in scalar registers (ng <= 512)
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 * GROUP_F floats
+
+    const int lane = threadIdx.x;
+    const int j = lane & 31;
+    const int h = lane >> 5;
+    const long pos0 = (long)blockIdx.x * (32 * NB);
+    const long ntile32 = (n + 31) / 32;
+
+    float xr[NB][D / 2];
+    float xn[NB];
+    float bestd[NB];
+    unsigned besti[NB];
+    long rowid[NB];
+    uint32_t mw[NB][MAXW];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        long pos = pos0 + 32 * b + j;
+        if (pos >= n) pos = n - 1;
+        const long r = (long)order[pos];
+        rowid[b] = r;
+        const f32x4* p = reinterpret_cast<const f32x4*>(X + r * D);
+        float nrm = 0.0f;
+#pragma unroll
+        for (int q = 0; q < D / 8; q++) {
+            const f32x4 u = p[2 * q], v = p[2 * q + 1];
+#pragma unroll
+            for (int e = 0; e < 4; e++) nrm = __builtin_fmaf(u[e], u[e], nrm);
+#pragma unroll
+            for (int e = 0; e < 4; e++) nrm = __builtin_fmaf(v[e], v[e], nrm);
+            xr[b][4 * q + 0] = h ? u[1] : u[0];
+            xr[b][4 * q + 1] = h ? u[3] : u[2];
+            xr[b][4 * q + 2] = h ? v[1] : v[0];
+            xr[b][4 * q + 3] = h ? v[3] : v[2];
+        }
+        xn[b] = nrm;
+        bestd[b] = bd_in[pos];
+        besti[b] = bestd[b] < __builtin_inff() ? hint_sorted[pos] : 0xffffffffu;
+        const long tile = pos0 / 32 + b;
+#pragma unroll
+        for (int w = 0; w < MAXW; w++) {
+            uint32_t m = 0;
+            if (w < ngw && tile < ntile32) m = mask[(size_t)tile * ngw + w];
+            mw[b][w] = __builtin_amdgcn_readfirstlane(m);
+        }
+    }
+    uint32_t any[MAXW];
+#pragma unroll
+    for (int w = 0; w < MAXW; w++) {
+        any[w] = 0;
+#pragma unroll
+        for (int b = 0; b < NB; b++) any[w] |= mw[b][w];
+    }
+    auto word_of = [&](const uint32_t (&m)[MAXW], int w) -> uint32_t {
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < MAXW; i++)
+            if (i == w) v = m[i];
+        return v;
+    };
+    auto next_group = [&](int from) {  // first needed group >= from, or ng
+        int w = from >> 5;
+        if (w >= ngw) return ng;
+        uint32_t bits = word_of(any, w) & (0xffffffffu << (from & 31));
+        while (bits == 0) {
+            if (++w >= ngw) return ng;
+            bits = word_of(any, w);
+        }
+        const int g = (w << 5) + __builtin_ctz(bits);
+        return g < ng ? g : ng;
+    };
+    auto stage_dma = [&](int g, float* dst) {
+        const float* src = img + (size_t)g * GROUP_F;
+#pragma unroll
+        for (int p = 0; p < PIECES; p++) dma_1k(src + p * 256 + lane * 4, dst + p * 256);
+    };
+
+    int g = next_group(0);
+    int buf = 0;
+    if (g < ng) stage_dma(g, smem);
+    const int swz = j & 15;
+    while (g < ng) {
+        const float* cur = smem + buf * GROUP_F;
+        // the group being consumed has landed once every DMA this wave issued so far is done; the
+        // reads of the other buffer (previous group) were all consumed by that group's MFMAs
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int nxt = next_group(g + 1);
+        if (nxt < ng) stage_dma(nxt, smem + (buf ^ 1) * GROUP_F);
+
+        f32x4 cnv[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) cnv[q] = *reinterpret_cast<const f32x4*>(cur + 32 * D + 8 * q + 4 * h);
+        const float* arow = cur + j * D;
+        const unsigned* idxrow = reinterpret_cast<const unsigned*>(cur) + 32 * D + 128 + 4 * h;
+        const uint32_t gbit = 1u << (g & 31);
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            if ((word_of(mw[b], g >> 5) & gbit) == 0u) continue;  // wave-uniform
+            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < D / 8; q++) {
+                const int pcx = (2 * q + h) ^ swz;
+                const f32x4 av = *reinterpret_cast<const f32x4*>(arow + pcx * 4);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], xr[b][4 * q + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], xr[b][4 * q + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], xr[b][4 * q + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], xr[b][4 * q + 3], acc, 0, 0, 0);
+            }
+            float m = __builtin_inff();
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float d0 = __builtin_fmaf(-2.0f, acc[r], xn[b] + cnv[r >> 2][r & 3]);
+                const float d1 = __builtin_fmaf(-2.0f, acc[r + 1], xn[b] + cnv[(r + 1) >> 2][(r + 1) & 3]);
+                m = __builtin_fminf(__builtin_fminf(m, d0), d1);
+            }
+            if (__builtin_amdgcn_ballot_w64(m <= bestd[b]) != 0) {
+                float bd = bestd[b];
+                unsigned bi = besti[b];
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float dd = __builtin_fmaxf(__builtin_fmaf(-2.0f, acc[r], xn[b] + cnv[r >> 2][r & 3]), 0.0f);
+                    const unsigned idx = idxrow[(r & 3) + 8 * (r >> 2)];
+                    const bool better = dd < bd || (dd == bd && idx < bi);
+                    bd = better ? dd : bd;
+                    bi = better ? idx : bi;
+                }
+                bestd[b] = bd;
+                besti[b] = bi;
+            }
+        }
+        g = nxt;
+        buf ^= 1;
+    }
+
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const float od = __shfl_xor(bestd[b], 32);
+        const unsigned oi = (unsigned)__shfl_xor((int)besti[b], 32);
+        float fd = bestd[b];
+        unsigned fi = besti[b];
+        if (od < fd || (od == fd && oi < fi)) {
+            fd = od;
+            fi = oi;
+        }
+        const long pos = pos0 + 32 * b + j;
+        if (h == 0 && pos < n) {
+            ids[rowid[b]] = fi == 0xffffffffu ? -1L : (long)fi;
+            if (dist) dist[rowid[b]] = fd;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Any d that is a multiple of 4 (n_mels other than 64/128, use_convolution's d = 10*n_mels):
 // the same MFMA sweep with the feature axis cut into chunks of 64.  The NA*NB accumulators of a
 // centroid tile stay live across the chunks (so every inner product is still ONE ascending fmaf
@@ -864,4 +1074,49 @@ extern "C" int at_assign_hinted_f32(at_ctx* ctx, const float* x, int64_t n, int 
                        reinterpret_cast<const long*>(hint_ids), hint_sorted, reinterpret_cast<long*>(ids), dist);
     AT_LAUNCH_CHECK();
     return AT_OK;
+}
+
+int at_prune_prepass(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
+                     const uint32_t* order, const uint32_t* hint_sorted, const float* dmin, int ng,
+                     float* bd_out, uint32_t* mask, int ngw, hipStream_t stream);
+
+template <int D, int NB>
+static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c, int k, const uint32_t* order,
+                         const uint32_t* hint_sorted, const int32_t* cperm, int ng, const float* dmin,
+                         int64_t* ids, float* dist, hipStream_t stream) {
+    const int kp = ng * 32;
+    const int ngw = (ng + 31) / 32;
+    const size_t img_bytes = sizeof(float) * (size_t)ng * tile_floats(D, 1);
+    const int64_t ntile32 = (n + 31) / 32;
+    float* img = static_cast<float*>(at_ws(ctx, WS_CENT_IMG, img_bytes, stream));
+    float* bd = static_cast<float*>(at_ws(ctx, WS_PRUNE_BD, sizeof(float) * (size_t)n, stream));
+    uint32_t* mask = static_cast<uint32_t*>(at_ws(ctx, WS_PRUNE_MASK, sizeof(uint32_t) * (size_t)ntile32 * ngw, stream));
+    if (!img || !bd || !mask) return AT_E_NOMEM;
+    // image: one tile per group (NA = 1): 32 rows, then |c|^2 at [0,32) and indices at [128,160)
+    hipLaunchKernelGGL(prep_centroids_perm_kernel, dim3(ng), dim3(WG), 0, stream, c, k, D, cperm, kp, 1, img);
+    AT_LAUNCH_CHECK();
+    int rc = at_prune_prepass(ctx, x, n, D, c, k, order, hint_sorted, dmin, ng, bd, mask, ngw, stream);
+    if (rc) return rc;
+    const size_t lds = 2 * sizeof(float) * tile_floats(D, 1);
+    const int64_t rows_per_wg = 32 * NB;
+    hipLaunchKernelGGL((assign_mfma_pruned_kernel<D, NB>), dim3((unsigned)((n + rows_per_wg - 1) / rows_per_wg)),
+                       dim3(64), lds, stream, x, (long)n, img, ng, order, hint_sorted, bd, mask, ngw,
+                       reinterpret_cast<long*>(ids), dist);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}
+
+extern "C" int at_assign_pruned_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
+                                    const uint32_t* order, const uint32_t* hint_sorted, const int32_t* cperm,
+                                    int ng, const float* dmin, int64_t* ids, float* dist, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AT_REQUIRE(ctx, "at_assign_pruned_f32: ctx is null");
+    AT_REQUIRE(x && c && order && hint_sorted && cperm && dmin && ids, "at_assign_pruned_f32: null pointer");
+    AT_REQUIRE(d == 64 || d == 128, "at_assign_pruned_f32: d must be 64 or 128");
+    AT_REQUIRE(n >= 20 && n < (int64_t)UINT32_MAX && k > 0 && ng > 0 && ng <= 512 && ng * 32 >= k,
+               "at_assign_pruned_f32: bad sizes n=%lld k=%d ng=%d", (long long)n, k, ng);
+    AT_REQUIRE(at_aligned16(x) && at_aligned16(c), "at_assign_pruned_f32: x and c must be 16-byte aligned");
+    AT_HIP(hipSetDevice(ctx->device));
+    if (d == 64) return launch_pruned<64, 2>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, ids, dist, stream);
+    return launch_pruned<128, 2>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, ids, dist, stream);
 }

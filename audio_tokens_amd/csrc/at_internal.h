@@ -19,6 +19,8 @@ enum at_ws_slot {
     WS_SEG_OFFSETS,    // centroid_accum: k+1 segment starts
     WS_REDUCE,         // at_sum_f32 / at_any_nonfinite partials
     WS_LOGMEL_FB,      // log-mel: banded filterbank tables
+    WS_PRUNE_BD,       // pruned sweep: exact distance to the guess, per visiting position
+    WS_PRUNE_MASK,     // pruned sweep: per 32-row tile, one bit per 32-centroid group
     WS_NSLOTS
 };
 

@@ -1,0 +1,243 @@
+// prune.hip -- the bookkeeping that lets a Lloyd iteration skip most of the -2XC^T work without
+// changing a single output bit (used by at_assign_pruned_f32, assign.hip).
+//
+// Replaces nothing in the reference by itself: it accelerates the search inside
+// faiss.Kmeans.train (processors/cluster_creator.py:54-56 of danavery/audio-tokens) from the second
+// Lloyd iteration on.
+//
+// Idea (Elkan's lemma, made safe for fp32): row x was assigned to centroid p in the previous
+// iteration; its distance to the UPDATED c_p is evaluated exactly (same fmaf chains as the MFMA
+// sweep) and is an upper bound bd of its final minimum.  For any other centroid c,
+// |x - c| >= |c - c_p| - |x - c_p|, so c cannot reach bd when |c - c_p| > 2 |x - c_p|.  To be
+// certain about the COMPUTED distances, which differ from the true ones by at most
+// delta = (2d + 8) u (|x|^2 + max|c|^2), the radius is inflated: R = sqrt(bd + delta), skip iff
+// (a lower bound of) |c - c_p| > 2 R.  Centroids are handled in groups of 32 (one MFMA
+// accumulator) laid out by a kd-style spatial grouping, rows in tiles of 32 visited in
+// (previous centroid, distance) order so that the outliers of a cluster sit together.
+//   group_min_dist_kernel : dmin[p][g] = lower bound of min_{c in group g} |c - c_p|
+//   visit order           : stable radix sort of (p << 8 | quantised distance, row)
+//   prune_mask_kernel     : per row bd; per 32-row tile one bit per group ("some row needs it")
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "at_internal.h"
+
+namespace {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int WG = 256;
+constexpr float U32 = 5.9604645e-8f;  // 2^-24
+
+// ---- dmin[p][g] ------------------------------------------------------------------------------
+// grid (ng, ceil(k/256)); the group's <= 32 rows sit in LDS (read as broadcasts); one thread per p
+// with its own row in registers.
+template <int D>
+__global__ void __launch_bounds__(WG) group_min_dist_kernel(const float* __restrict__ C, int k,
+                                                            const int32_t* __restrict__ cperm, int ng,
+                                                            float* __restrict__ dmin) {
+    __shared__ __attribute__((aligned(16))) float grp[32 * D];
+    __shared__ int member[32];
+    const int g = blockIdx.x;
+    if (threadIdx.x < 32) member[threadIdx.x] = cperm[g * 32 + threadIdx.x];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * (D / 4); e += WG) {
+        const int m = member[e / (D / 4)];
+        f32x4_t v = {0, 0, 0, 0};
+        if (m >= 0) v = reinterpret_cast<const f32x4_t*>(C + (size_t)m * D)[e % (D / 4)];
+        reinterpret_cast<f32x4_t*>(grp)[e] = v;
+    }
+    __syncthreads();
+    int p = blockIdx.y * WG + threadIdx.x;
+    const bool livep = p < k;
+    if (!livep) p = k - 1;
+    f32x4_t cp[D / 4];
+#pragma unroll
+    for (int q = 0; q < D / 4; q++) cp[q] = reinterpret_cast<const f32x4_t*>(C + (size_t)p * D)[q];
+    float best = __builtin_inff();
+    for (int m = 0; m < 32; m++) {
+        if (member[m] < 0) continue;  // uniform
+        const f32x4_t* cg = reinterpret_cast<const f32x4_t*>(grp + m * D);
+        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < D / 4; q++) {
+            const f32x4_t b = cg[q];
+            const float d0 = cp[q][0] - b[0], d1 = cp[q][1] - b[1], d2 = cp[q][2] - b[2], d3 = cp[q][3] - b[3];
+            s0 = __builtin_fmaf(d0, d0, s0);
+            s1 = __builtin_fmaf(d1, d1, s1);
+            s0 = __builtin_fmaf(d2, d2, s0);
+            s1 = __builtin_fmaf(d3, d3, s1);
+        }
+        best = fminf(best, s0 + s1);
+    }
+    // the fp32 sum of squared fp32 differences is within (d+3)u of the true value: shave 2e-5
+    if (livep) dmin[(size_t)p * ng + g] = best == __builtin_inff() ? best : sqrtf(best) * (1.0f - 2e-5f);
+}
+
+// ---- visiting order --------------------------------------------------------------------------
+__global__ void __launch_bounds__(WG) visit_keys_kernel(const long* __restrict__ ids,
+                                                        const float* __restrict__ dis, long n, int k,
+                                                        uint32_t* __restrict__ keys,
+                                                        uint32_t* __restrict__ vals) {
+    const long i = (long)blockIdx.x * WG + threadIdx.x;
+    if (i >= n) return;
+    const long c = ids[i];
+    const bool ok = c >= 0 && c < k;
+    float r = dis ? sqrtf(fmaxf(dis[i], 0.0f)) * 127.0f : 0.0f;   // unit rows: r <= 2
+    r = fminf(r, 255.0f);
+    keys[i] = ((ok ? (uint32_t)c : (uint32_t)k) << 8) | (uint32_t)r;
+    vals[i] = (uint32_t)i;
+}
+
+__global__ void __launch_bounds__(WG) key_to_hint_kernel(const uint32_t* __restrict__ keys, long n,
+                                                         uint32_t* __restrict__ hint_sorted) {
+    const long i = (long)blockIdx.x * WG + threadIdx.x;
+    if (i < n) hint_sorted[i] = keys[i] >> 8;
+}
+
+__global__ void __launch_bounds__(WG) max_sqnorm_kernel(const float* __restrict__ C, int k, int d,
+                                                        unsigned* __restrict__ out_bits) {
+    const int c = blockIdx.x * WG + threadIdx.x;
+    float s = 0.0f;
+    if (c < k)
+        for (int f = 0; f < d; f++) s = __builtin_fmaf(C[(size_t)c * d + f], C[(size_t)c * d + f], s);
+    // non-negative floats order like their bit patterns
+    atomicMax(out_bits, __float_as_uint(s));
+}
+
+// ---- per-row bound and per-tile group mask ----------------------------------------------------
+// One wave per 64 visiting positions (two 32-row tiles: lanes 0-31 and 32-63).
+template <int D>
+__global__ void __launch_bounds__(WG) prune_mask_kernel(const float* __restrict__ X, long n,
+                                                        const float* __restrict__ C, int k,
+                                                        const uint32_t* __restrict__ order,
+                                                        const uint32_t* __restrict__ hint_sorted,
+                                                        const float* __restrict__ dmin, int ng,
+                                                        const unsigned* __restrict__ cnmax_bits,
+                                                        float* __restrict__ bd_out,
+                                                        uint32_t* __restrict__ mask, int ngw) {
+    const int lane = threadIdx.x & 63;
+    const long wpos = ((long)blockIdx.x * (WG / 64) + (threadIdx.x >> 6)) * 64;
+    if (wpos >= n) return;
+    long pos = wpos + lane;
+    const bool live = pos < n;
+    if (!live) pos = n - 1;
+    const long r = order[pos];
+    const uint32_t p = hint_sorted[pos];
+    const bool has = p < (uint32_t)k;
+    const f32x4_t* px = reinterpret_cast<const f32x4_t*>(X + r * D);
+    const f32x4_t* pc = reinterpret_cast<const f32x4_t*>(C + (size_t)(has ? p : 0) * D);
+    float xn = 0.0f, cn = 0.0f, ip = 0.0f;
+#pragma clang loop unroll(disable)
+    for (int q = 0; q < D / 4; q++) {
+        const f32x4_t u = px[q], cu = pc[q];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            xn = __builtin_fmaf(u[e], u[e], xn);
+            cn = __builtin_fmaf(cu[e], cu[e], cn);
+            ip = __builtin_fmaf(cu[e], u[e], ip);
+        }
+    }
+    // exactly the value the MFMA sweep would produce for (x, c_p)
+    const float dh = __builtin_fmaxf(__builtin_fmaf(-2.0f, ip, xn + cn), 0.0f);
+    if (live) bd_out[pos] = has ? dh : __builtin_inff();
+
+    const float cnmax = __uint_as_float(*cnmax_bits);
+    const float delta = (2.0f * D + 8.0f) * U32 * (xn + cnmax) * 1.01f;
+    // rows without a guess need every group; positions past n need none
+    const float tau = !live ? -1.0f
+                            : (has ? 2.0f * sqrtf(dh + delta) * (1.0f + 4.0f * U32) + 1e-30f : __builtin_inff());
+
+    const float* drow = dmin + (size_t)(has ? p : 0) * ng;
+    const long tile = wpos / 32;
+    const bool second = wpos + 32 < n;
+    for (int w = 0; w < ngw; w++) {
+        uint32_t bitsA = 0, bitsB = 0;
+        const int g1 = min(32, ng - 32 * w);
+        for (int gg = 0; gg < g1; gg++) {
+            const bool need = drow[32 * w + gg] <= tau;     // +inf tau: always; dead lane: never
+            const unsigned long long b = __builtin_amdgcn_ballot_w64(need);
+            bitsA |= (uint32_t)((b & 0xffffffffull) != 0) << gg;
+            bitsB |= (uint32_t)((b >> 32) != 0) << gg;
+        }
+        if (lane == 0) {
+            mask[(size_t)tile * ngw + w] = bitsA;
+            if (second) mask[(size_t)(tile + 1) * ngw + w] = bitsB;
+        }
+    }
+}
+
+}  // namespace
+
+// ---- entry points used by assign.hip and the C ABI -------------------------------------------
+int at_prune_prepass(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
+                     const uint32_t* order, const uint32_t* hint_sorted, const float* dmin, int ng,
+                     float* bd_out, uint32_t* mask, int ngw, hipStream_t stream) {
+    unsigned* cnmax = static_cast<unsigned*>(at_ws(ctx, WS_REDUCE, 1024 * sizeof(double), stream));
+    if (!cnmax) return AT_E_NOMEM;
+    AT_HIP(hipMemsetAsync(cnmax, 0, sizeof(unsigned), stream));
+    hipLaunchKernelGGL(max_sqnorm_kernel, dim3((k + WG - 1) / WG), dim3(WG), 0, stream, c, k, d, cnmax);
+    AT_LAUNCH_CHECK();
+    const long waves = (n + 63) / 64;
+    const dim3 grid((unsigned)((waves + WG / 64 - 1) / (WG / 64)));
+    if (d == 64)
+        hipLaunchKernelGGL(prune_mask_kernel<64>, grid, dim3(WG), 0, stream, x, (long)n, c, k, order, hint_sorted,
+                           dmin, ng, cnmax, bd_out, mask, ngw);
+    else
+        hipLaunchKernelGGL(prune_mask_kernel<128>, grid, dim3(WG), 0, stream, x, (long)n, c, k, order, hint_sorted,
+                           dmin, ng, cnmax, bd_out, mask, ngw);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}
+
+extern "C" {
+
+int at_group_min_dist_f32(at_ctx* ctx, const float* c, int k, int d, const int32_t* cperm, int ng,
+                          float* dmin, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AT_REQUIRE(ctx && c && cperm && dmin && k > 0 && d > 0 && ng > 0, "at_group_min_dist_f32: bad arguments");
+    AT_REQUIRE((d == 64 || d == 128) && at_aligned16(c), "at_group_min_dist_f32: d must be 64 or 128");
+    AT_HIP(hipSetDevice(ctx->device));
+    const dim3 grid(ng, (k + WG - 1) / WG);
+    if (d == 64)
+        hipLaunchKernelGGL(group_min_dist_kernel<64>, grid, dim3(WG), 0, stream, c, k, cperm, ng, dmin);
+    else
+        hipLaunchKernelGGL(group_min_dist_kernel<128>, grid, dim3(WG), 0, stream, c, k, cperm, ng, dmin);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}
+
+int at_visit_order_f32(at_ctx* ctx, const int64_t* ids, const float* dis, int64_t n, int k,
+                       uint32_t* order_out, uint32_t* hint_sorted_out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AT_REQUIRE(ctx && ids && order_out && hint_sorted_out, "at_visit_order_f32: null pointer");
+    AT_REQUIRE(n >= 0 && n < (int64_t)UINT32_MAX && k > 0 && k < (1 << 23), "at_visit_order_f32: bad sizes");
+    if (n == 0) return AT_OK;
+    AT_HIP(hipSetDevice(ctx->device));
+    uint32_t* keys_a = static_cast<uint32_t*>(at_ws(ctx, WS_SORT_KEYS_A, (size_t)n * 4, stream));
+    uint32_t* keys_b = static_cast<uint32_t*>(at_ws(ctx, WS_SORT_KEYS_B, (size_t)n * 4, stream));
+    uint32_t* vals_a = static_cast<uint32_t*>(at_ws(ctx, WS_SORT_VALS_A, (size_t)n * 4, stream));
+    uint32_t* vals_b = static_cast<uint32_t*>(at_ws(ctx, WS_SORT_VALS_B, (size_t)n * 4, stream));
+    if (!keys_a || !keys_b || !vals_a || !vals_b) return AT_E_NOMEM;
+    hipLaunchKernelGGL(visit_keys_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, stream,
+                       reinterpret_cast<const long*>(ids), dis, (long)n, k, keys_a, vals_a);
+    AT_LAUNCH_CHECK();
+    unsigned bits = 1;
+    while ((1u << bits) <= (unsigned)k) bits++;
+    bits += 8;
+    rocprim::double_buffer<uint32_t> kb(keys_a, keys_b);
+    rocprim::double_buffer<uint32_t> vb(vals_a, vals_b);
+    size_t tmp_bytes = 0;
+    AT_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kb, vb, (size_t)n, 0, bits, stream));
+    void* tmp = at_ws(ctx, WS_SORT_TMP, tmp_bytes, stream);
+    if (!tmp) return AT_E_NOMEM;
+    AT_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, kb, vb, (size_t)n, 0, bits, stream));
+    AT_HIP(hipMemcpyAsync(order_out, vb.current(), sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL(key_to_hint_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, stream, kb.current(),
+                       (long)n, hint_sorted_out);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}
+
+}  // extern "C"

@@ -183,6 +183,7 @@ class Kmeans:
         self.iteration_stats = []
         self.index = None
         self.phase_seconds = None
+        self.prune = True  # exact pruning of Lloyd iterations 2..niter (d = 64 / 128 only)
 
     # ------------------------------------------------------------------------------------
     def train(self, x, init_centroids=None):
@@ -264,17 +265,30 @@ class Kmeans:
             prof[name] = prof.get(name, 0.0) + (now - t_prev)
             return now
 
-        ids = order = None
+        # Iterations after the first reuse the previous assignment as a guess.  With d = 64/128 the
+        # sweep is also pruned (exact: see csrc/prune.hip); the spatial grouping of the centroids it
+        # relies on is computed once per train() -- it only affects how much gets skipped.
+        prune = (self.prune and hasattr(be, "assign_pruned") and d in (64, 128) and k >= 64
+                 and (k + 31) // 32 <= 512 and xs.shape[0] >= 20)
+        ids = dis = order = cperm = None
         for it in range(self.niter):
             ts = time.time()
             tp = time.perf_counter()
             if ids is None:
                 ids, dis = be.assign(xs, cent)
+            elif prune:
+                if cperm is None:
+                    cperm = be.from_host(be.group_rows_kd(be.to_host(cent)))
+                dmin = be.group_min_dist(cent, cperm)
+                ids, dis = be.assign_pruned(xs, cent, be.visit_order(ids, dis, k), cperm, dmin)
             else:  # same answer, guided by the previous assignment and its member-list order
                 ids, dis = be.assign_hinted(xs, cent, ids, order)
             tp = lap("assign", tp)
             obj = dist.sum_f64(be.sum_f64(dis))
-            part, order = be.centroid_accum(xs, ids, k, want_order=True)
+            if prune:
+                part = be.centroid_accum(xs, ids, k)
+            else:
+                part, order = be.centroid_accum(xs, ids, k, want_order=True)
             tp = lap("accumulate", tp)
             parts = dist.all_gather_parts(part)
             cent, hassign = be.centroid_finalize(parts, k, d)

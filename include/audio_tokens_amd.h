@@ -116,6 +116,26 @@ int at_assign_hinted_f32(at_ctx* ctx, const float* x, int64_t n, int d, const fl
                          const uint32_t* hint_sorted_or_null, int64_t* ids, float* dist_or_null,
                          void* stream);
 
+/* ---- exact pruning for Lloyd iterations (none of this changes any result) ----------------------
+ * at_group_rows_kd_host: spatial grouping of the centroid table into groups of `leaf` rows (host
+ *   arrays; perm_out: ceil(k/leaf)*leaf entries, -1 padded).
+ * at_group_min_dist_f32: dmin[p][g] (DEVICE float [k][ng]) = a lower bound of the distance from
+ *   centroid p to the nearest member of group g (groups of 32 as listed in cperm, DEVICE int32).
+ * at_visit_order_f32: rows sorted by (previous id, previous distance): order_out and the ids in
+ *   that order (both DEVICE uint32 [n]).
+ * at_assign_pruned_f32: the answer of at_assign_f32, bit for bit (d = 64 or 128, n >= 20,
+ *   ng <= 512).  Every row's guess hint_sorted[p] (for row order[p]) is scored exactly first; a
+ *   32-centroid group is then skipped for a 32-row tile when the triangle inequality, with a margin
+ *   that covers the fp32 rounding of the distances, rules it out for all of the tile's rows. */
+int at_group_rows_kd_host(const float* rows_host, int k, int d, int leaf, int32_t* perm_out_host);
+int at_group_min_dist_f32(at_ctx* ctx, const float* c, int k, int d, const int32_t* cperm, int ng,
+                          float* dmin, void* stream);
+int at_visit_order_f32(at_ctx* ctx, const int64_t* ids, const float* dis_or_null, int64_t n, int k,
+                       uint32_t* order_out, uint32_t* hint_sorted_out, void* stream);
+int at_assign_pruned_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
+                         const uint32_t* order, const uint32_t* hint_sorted, const int32_t* cperm,
+                         int ng, const float* dmin, int64_t* ids, float* dist_or_null, void* stream);
+
 /* out[i] = x[idx[i]] (rows of d floats).  idx: DEVICE int32 [m]. */
 int at_gather_rows_f32(at_ctx* ctx, const float* x, int d, const int32_t* idx, int64_t m,
                        float* out, void* stream);

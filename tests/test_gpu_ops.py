@@ -76,6 +76,50 @@ def test_assign_hinted_is_hint_independent(be, oracle, n, d, k):
     assert np.array_equal(sorted_ids.cpu().numpy().view(np.uint32), ids_o[ref_order].astype(np.uint32))
 
 
+@pytest.mark.parametrize("n,d,k", [(6000, 64, 300), (70000, 64, 8192), (3000, 128, 1000), (50000, 128, 4096),
+                                   (20000, 64, 2048)])
+def test_assign_pruned_is_exact(be, oracle, n, d, k):
+    """at_assign_pruned_f32 == brute force, bit for bit, for good guesses (where it prunes), bad
+    guesses, missing guesses and exact ties."""
+    rng = np.random.default_rng(n * 3 + d + k)
+    # clustered data so that pruning actually happens
+    centers = _unit_rows(rng, k, d, oracle)
+    x = oracle.l2norm_rows((centers[rng.integers(0, k, n)] + 0.05 * rng.standard_normal((n, d))).astype(np.float32))
+    c = oracle.l2norm_rows((centers + 0.01 * rng.standard_normal((k, d))).astype(np.float32))
+    c[k // 2: k // 2 + 20] = c[0:20]
+    x[:20] = c[k // 2: k // 2 + 20]
+    ids_o, dis_o = oracle.assign(x, c)
+    xt, ct = be._f32(x), be._f32(c)
+    cperm = be.from_host(be.group_rows_kd(c))
+    dmin = be.group_min_dist(ct, cperm)
+    # dmin really is a lower bound of the true distances
+    cp = cperm.cpu().numpy().reshape(-1, 32)
+    for g in (0, cp.shape[0] // 2, cp.shape[0] - 1):
+        mem = cp[g][cp[g] >= 0]
+        true = np.sqrt(((c[:, None, :].astype(np.float64) - c[None, mem].astype(np.float64)) ** 2).sum(-1)).min(1)
+        assert (dmin[:, g].cpu().numpy() <= true + 1e-12).all()
+    truth = torch.from_numpy(ids_o).to(be.device)
+    dtruth = torch.from_numpy(dis_o).to(be.device)
+    cases = {
+        "truth": (truth, dtruth),
+        "random": (torch.from_numpy(rng.integers(0, k, n)).to(be.device), None),
+        "none": (torch.full((n,), -1, dtype=torch.int64, device=be.device), None),
+        "dup_high": (torch.where(truth < 20, truth + k // 2, truth), dtruth),
+        "mixed": (torch.where(torch.arange(n, device=be.device) % 5 == 0, (truth + 11) % k, truth), dtruth),
+    }
+    for name, (hint, hd) in cases.items():
+        order = be.visit_order(hint.contiguous(), hd, k)
+        ids, dis = be.assign_pruned(xt, ct, order, cperm, dmin)
+        assert np.array_equal(ids.cpu().numpy(), ids_o), f"hint={name}: {(ids.cpu().numpy() != ids_o).sum()} ids differ"
+        assert np.array_equal(bits(dis.cpu().numpy()), bits(dis_o)), name
+    # the visiting order is a permutation sorted by guess
+    order, hs = be.visit_order(truth, dtruth, k)
+    o = order.cpu().numpy().view(np.uint32).astype(np.int64)
+    assert np.array_equal(np.sort(o), np.arange(n))
+    assert np.array_equal(hs.cpu().numpy().view(np.uint32), ids_o[o].astype(np.uint32))
+    assert (np.diff(ids_o[o]) >= 0).all()
+
+
 @pytest.mark.parametrize("n", [1, 5, 19])
 def test_assign_small_batch_form(be, oracle, n):
     rng = np.random.default_rng(n)
