@@ -230,26 +230,65 @@ class HipBackend(HostHelpers):
                                                    self._stream()))
         return order, hs
 
-    def assign_pruned(self, x, c, order, cperm, dmin, want_dist=True):
-        """Same result as assign(); `order` = visit_order(...) of the previous assignment."""
+    def group_means(self, c, cperm) -> torch.Tensor:
+        c = self._f32(c)
+        k, d = c.shape
+        ng = cperm.numel() // 32
+        means = self.empty((ng, d))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_group_means_f32(self.ctx.handle, _ptr(c), k, d, _ptr(cperm), ng, _ptr(means),
+                                                   self._stream()))
+        return means
+
+    def group_neighbours(self, means, nnb=4) -> torch.Tensor:
+        """[ng, ceil(ng/32)] bit table: for every group the nnb groups with the nearest means
+        (itself included).  Heuristic input of the coarse pass; host side, tiny."""
+        m = self.to_host(means).astype(np.float32)
+        ng = m.shape[0]
+        sq = (m * m).sum(1)
+        d2 = sq[:, None] + sq[None, :] - 2.0 * (m @ m.T)
+        np.fill_diagonal(d2, -1.0)                                  # a group is its own first neighbour
+        nb = np.argsort(d2, axis=1, kind="stable")[:, :min(nnb, ng)]
+        ngw = (ng + 31) // 32
+        bits = np.zeros((ng, ngw), np.uint32)
+        rows = np.repeat(np.arange(ng), nb.shape[1])
+        np.bitwise_or.at(bits, (rows, (nb >> 5).ravel()), (np.uint32(1) << (nb & 31).astype(np.uint32)).ravel())
+        return self.from_host(bits.view(np.int32))
+
+    def assign_c2f(self, x, c, cperm, dmin, gnbr=None, want_dist=True):
+        """Exact nearest centroid without guesses: nearest group mean -> best member of that group
+        and its neighbour groups (a guess) -> pruned exact sweep.  Same result as assign()."""
+        x, c = self._f32(x), self._f32(c)
+        ng = cperm.numel() // 32
+        means = self.group_means(c, cperm)
+        if gnbr is None:
+            gnbr = self.group_neighbours(means)
+        gx, _ = self.assign(x, means, want_dist=False)
+        guess, gdis = self.assign_pruned(x, c, self.visit_order(gx, None, ng), cperm, gnbr, mode=1)
+        return self.assign_pruned(x, c, self.visit_order(guess, gdis, c.shape[0]), cperm, dmin, want_dist=want_dist)
+
+    def assign_pruned(self, x, c, order, cperm, dmin, want_dist=True, mode=0):
+        """mode 0: same result as assign(); `order` = visit_order(...) of the guesses.
+        mode 1: best centroid among the groups named by each 32-row tile (order = visit_order of
+        group ids) -- a guess generator."""
         x, c = self._f32(x), self._f32(c)
         n, d = x.shape
         k = c.shape[0]
         order, hint_sorted = order
         ng = cperm.numel() // 32
         ids = self.empty((n,), torch.int64)
-        dist = self.empty((n,), torch.float32) if want_dist else None
+        dist = self.empty((n,), torch.float32) if (want_dist or mode == 1) else None
         rec = self.assign_trace
         if rec is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.device))
         with torch.cuda.device(self.device):
             _lib.check(self.lib.at_assign_pruned_f32(self.ctx.handle, _ptr(x), n, d, _ptr(c), k, _ptr(order),
-                                                     _ptr(hint_sorted), _ptr(cperm), ng, _ptr(dmin), _ptr(ids),
+                                                     _ptr(hint_sorted), _ptr(cperm), ng, _ptr(dmin), mode, _ptr(ids),
                                                      _ptr(dist), self._stream()))
         if rec is not None:
             e1.record(torch.cuda.current_stream(self.device))
-            rec.append(("pruned", n, d, k, e0, e1))
+            rec.append(("pruned" if mode == 0 else "coarse", n, d, k, e0, e1))
         return ids, dist
 
     def gather_rows(self, x, idx) -> torch.Tensor:

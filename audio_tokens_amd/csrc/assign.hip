@@ -1078,11 +1078,11 @@ extern "C" int at_assign_hinted_f32(at_ctx* ctx, const float* x, int64_t n, int 
 
 int at_prune_prepass(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
                      const uint32_t* order, const uint32_t* hint_sorted, const float* dmin, int ng,
-                     float* bd_out, uint32_t* mask, int ngw, hipStream_t stream);
+                     float* bd_out, uint32_t* mask, int ngw, int mode, hipStream_t stream);
 
 template <int D, int NB>
 static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c, int k, const uint32_t* order,
-                         const uint32_t* hint_sorted, const int32_t* cperm, int ng, const float* dmin,
+                         const uint32_t* hint_sorted, const int32_t* cperm, int ng, const float* dmin, int mode,
                          int64_t* ids, float* dist, hipStream_t stream) {
     const int kp = ng * 32;
     const int ngw = (ng + 31) / 32;
@@ -1095,7 +1095,7 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
     // image: one tile per group (NA = 1): 32 rows, then |c|^2 at [0,32) and indices at [128,160)
     hipLaunchKernelGGL(prep_centroids_perm_kernel, dim3(ng), dim3(WG), 0, stream, c, k, D, cperm, kp, 1, img);
     AT_LAUNCH_CHECK();
-    int rc = at_prune_prepass(ctx, x, n, D, c, k, order, hint_sorted, dmin, ng, bd, mask, ngw, stream);
+    int rc = at_prune_prepass(ctx, x, n, D, c, k, order, hint_sorted, dmin, ng, bd, mask, ngw, mode, stream);
     if (rc) return rc;
     const size_t lds = 2 * sizeof(float) * tile_floats(D, 1);
     const int64_t rows_per_wg = 32 * NB;
@@ -1108,15 +1108,22 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
 
 extern "C" int at_assign_pruned_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
                                     const uint32_t* order, const uint32_t* hint_sorted, const int32_t* cperm,
-                                    int ng, const float* dmin, int64_t* ids, float* dist, void* stream_) {
+                                    int ng, const float* dmin, int mode, int64_t* ids, float* dist,
+                                    void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     AT_REQUIRE(ctx, "at_assign_pruned_f32: ctx is null");
-    AT_REQUIRE(x && c && order && hint_sorted && cperm && dmin && ids, "at_assign_pruned_f32: null pointer");
+    AT_REQUIRE(x && c && order && hint_sorted && cperm && (dmin || mode == 1) && ids, "at_assign_pruned_f32: null pointer");
+    AT_REQUIRE(mode == 0 || mode == 1, "at_assign_pruned_f32: mode must be 0 or 1");
     AT_REQUIRE(d == 64 || d == 128, "at_assign_pruned_f32: d must be 64 or 128");
     AT_REQUIRE(n >= 20 && n < (int64_t)UINT32_MAX && k > 0 && ng > 0 && ng <= 512 && ng * 32 >= k,
                "at_assign_pruned_f32: bad sizes n=%lld k=%d ng=%d", (long long)n, k, ng);
     AT_REQUIRE(at_aligned16(x) && at_aligned16(c), "at_assign_pruned_f32: x and c must be 16-byte aligned");
     AT_HIP(hipSetDevice(ctx->device));
-    if (d == 64) return launch_pruned<64, 2>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, ids, dist, stream);
-    return launch_pruned<128, 2>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, ids, dist, stream);
+    if (d == 64) {
+        const char* e = std::getenv("AT_PRUNE_NB");
+        if (e && std::atoi(e) == 4) return launch_pruned<64, 4>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, ids, dist, stream);
+        if (e && std::atoi(e) == 1) return launch_pruned<64, 1>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, ids, dist, stream);
+        return launch_pruned<64, 2>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, ids, dist, stream);
+    }
+    return launch_pruned<128, 2>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, ids, dist, stream);
 }

@@ -168,12 +168,64 @@ __global__ void __launch_bounds__(WG) prune_mask_kernel(const float* __restrict_
     }
 }
 
+// Coarse step of the unguided search: every row names one group (hint_sorted holds GROUP ids here);
+// the tile needs exactly the groups its rows name, and nobody has a running best yet.
+__global__ void __launch_bounds__(WG) group_only_mask_kernel(long n, const uint32_t* __restrict__ group_sorted,
+                                                             int ng, const uint32_t* __restrict__ gnbr,
+                                                             float* __restrict__ bd_out,
+                                                             uint32_t* __restrict__ mask, int ngw) {
+    const int lane = threadIdx.x & 63;
+    const long wpos = ((long)blockIdx.x * (WG / 64) + (threadIdx.x >> 6)) * 64;
+    if (wpos >= n) return;
+    const long pos = wpos + lane;
+    const bool live = pos < n;
+    const uint32_t g = live ? group_sorted[pos] : 0xffffffffu;
+    if (live) bd_out[pos] = __builtin_inff();
+    const long tile = wpos / 32;
+    const bool second = wpos + 32 < n;
+    for (int w = 0; w < ngw; w++) {
+        // OR of (1 << bit) over the lanes of each half-wave whose group falls into word w
+        // gnbr (optional, [ng][ngw]): the groups worth searching for a row that names group g
+        uint32_t mine = 0u;
+        if (live && g < (uint32_t)ng)
+            mine = gnbr ? gnbr[(size_t)g * ngw + w] : ((int)(g >> 5) == w ? (1u << (g & 31)) : 0u);
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) mine |= (uint32_t)__shfl_xor((int)mine, off);
+        if (lane == 0) mask[(size_t)tile * ngw + w] = mine;
+        if (lane == 32 && second) mask[(size_t)(tile + 1) * ngw + w] = mine;
+    }
+}
+
+// means[g] = mean of the group's member rows (coarse quantiser of the unguided search)
+__global__ void __launch_bounds__(WG) group_means_kernel(const float* __restrict__ C, int d,
+                                                         const int32_t* __restrict__ cperm,
+                                                         float* __restrict__ means) {
+    const int g = blockIdx.x;
+    for (int f = threadIdx.x; f < d; f += WG) {
+        float s = 0.0f;
+        int cnt = 0;
+        for (int m = 0; m < 32; m++) {
+            const int row = cperm[g * 32 + m];
+            if (row >= 0) { s += C[(size_t)row * d + f]; cnt++; }
+        }
+        means[(size_t)g * d + f] = cnt ? s / (float)cnt : 0.0f;
+    }
+}
+
 }  // namespace
 
 // ---- entry points used by assign.hip and the C ABI -------------------------------------------
 int at_prune_prepass(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
                      const uint32_t* order, const uint32_t* hint_sorted, const float* dmin, int ng,
-                     float* bd_out, uint32_t* mask, int ngw, hipStream_t stream) {
+                     float* bd_out, uint32_t* mask, int ngw, int mode, hipStream_t stream) {
+    if (mode == 1) {  // hint_sorted holds group ids: each tile needs just those groups (+ neighbours)
+        const long waves1 = (n + 63) / 64;
+        hipLaunchKernelGGL(group_only_mask_kernel, dim3((unsigned)((waves1 + WG / 64 - 1) / (WG / 64))), dim3(WG), 0,
+                           stream, (long)n, hint_sorted, ng, reinterpret_cast<const uint32_t*>(dmin), bd_out, mask,
+                           ngw);
+        AT_LAUNCH_CHECK();
+        return AT_OK;
+    }
     unsigned* cnmax = static_cast<unsigned*>(at_ws(ctx, WS_REDUCE, 1024 * sizeof(double), stream));
     if (!cnmax) return AT_E_NOMEM;
     AT_HIP(hipMemsetAsync(cnmax, 0, sizeof(unsigned), stream));
@@ -204,6 +256,16 @@ int at_group_min_dist_f32(at_ctx* ctx, const float* c, int k, int d, const int32
         hipLaunchKernelGGL(group_min_dist_kernel<64>, grid, dim3(WG), 0, stream, c, k, cperm, ng, dmin);
     else
         hipLaunchKernelGGL(group_min_dist_kernel<128>, grid, dim3(WG), 0, stream, c, k, cperm, ng, dmin);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}
+
+int at_group_means_f32(at_ctx* ctx, const float* c, int k, int d, const int32_t* cperm, int ng, float* means,
+                       void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AT_REQUIRE(ctx && c && cperm && means && k > 0 && d > 0 && ng > 0, "at_group_means_f32: bad arguments");
+    AT_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(group_means_kernel, dim3(ng), dim3(WG), 0, stream, c, d, cperm, means);
     AT_LAUNCH_CHECK();
     return AT_OK;
 }

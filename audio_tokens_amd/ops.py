@@ -268,19 +268,26 @@ class Kmeans:
         # Iterations after the first reuse the previous assignment as a guess.  With d = 64/128 the
         # sweep is also pruned (exact: see csrc/prune.hip); the spatial grouping of the centroids it
         # relies on is computed once per train() -- it only affects how much gets skipped.
-        prune = (self.prune and hasattr(be, "assign_pruned") and d in (64, 128) and k >= 64
-                 and (k + 31) // 32 <= 512 and xs.shape[0] >= 20)
-        ids = dis = order = cperm = None
+        prune = (self.prune and hasattr(be, "assign_pruned") and d in (64, 128) and k >= 1024
+                 and (k + 31) // 32 <= 512 and xs.shape[0] >= 4096)
+        ids = dis = order = None
+        if prune:  # grouping from the initial centroids, kept for the whole train()
+            cperm = be.from_host(be.group_rows_kd(be.to_host(cent)))
+            gnbr = None
         for it in range(self.niter):
             ts = time.time()
             tp = time.perf_counter()
-            if ids is None:
-                ids, dis = be.assign(xs, cent)
-            elif prune:
-                if cperm is None:
+            if prune:
+                if it == 2 and init_centroids is None:  # cold start: regroup once the centroids have settled
                     cperm = be.from_host(be.group_rows_kd(be.to_host(cent)))
                 dmin = be.group_min_dist(cent, cperm)
-                ids, dis = be.assign_pruned(xs, cent, be.visit_order(ids, dis, k), cperm, dmin)
+                if ids is None:   # no previous assignment yet: coarse-to-fine exact search
+                    gnbr = be.group_neighbours(be.group_means(cent, cperm), 8)
+                    ids, dis = be.assign_c2f(xs, cent, cperm, dmin, gnbr)
+                else:
+                    ids, dis = be.assign_pruned(xs, cent, be.visit_order(ids, dis, k), cperm, dmin)
+            elif ids is None:
+                ids, dis = be.assign(xs, cent)
             else:  # same answer, guided by the previous assignment and its member-list order
                 ids, dis = be.assign_hinted(xs, cent, ids, order)
             tp = lap("assign", tp)
@@ -332,6 +339,8 @@ class IndexFlatL2:
         self.d = int(d)
         self.backend = backend or default_backend()
         self._c = None
+        self._prune = None   # (cperm, dmin, gnbr) for the coarse-to-fine exact search, built lazily
+        self.prune = True
 
     @property
     def ntotal(self) -> int:
@@ -339,11 +348,28 @@ class IndexFlatL2:
 
     def reset(self) -> None:
         self._c = None
+        self._prune = None
 
     def add(self, c) -> None:
         c = self.backend._f32(c)
         assert c.dim() == 2 and c.shape[1] == self.d, f"expected [n, {self.d}]"
         self._c = c.clone() if self._c is None else torch.cat([self._c, c], 0)
+        self._prune = None
+
+    def assign(self, x, want_dist=True):
+        """Device tensors in, (ids [n] int64, dis [n] float32 or None) out: the search itself.  Large
+        searches against large tables go through the exact coarse-to-fine pruned sweep."""
+        be = self.backend
+        c = self._c
+        k = c.shape[0]
+        if (self.prune and hasattr(be, "assign_c2f") and self.d in (64, 128) and k >= 1024
+                and (k + 31) // 32 <= 512 and x.shape[0] >= 65536):
+            if self._prune is None:
+                cperm = be.from_host(be.group_rows_kd(be.to_host(c)))
+                self._prune = (cperm, be.group_min_dist(c, cperm), be.group_neighbours(be.group_means(c, cperm), 8))
+            cperm, dmin, gnbr = self._prune
+            return be.assign_c2f(x, c, cperm, dmin, gnbr, want_dist=want_dist)
+        return be.assign(x, c, want_dist=want_dist)
 
     def search(self, x, k=1):
         if k != 1:
@@ -356,6 +382,6 @@ class IndexFlatL2:
             D = torch.full((x.shape[0], 1), float("inf"), device=be.device)
             I = torch.full((x.shape[0], 1), -1, dtype=torch.int64, device=be.device)
         else:
-            ids, dis = be.assign(x, self._c)
+            ids, dis = self.assign(x)
             D, I = dis.unsqueeze(1), ids.unsqueeze(1)
         return (be.to_host(D), be.to_host(I)) if host else (D, I)

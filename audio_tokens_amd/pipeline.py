@@ -22,7 +22,7 @@ from dataclasses import dataclass, field
 import torch
 
 from .backend import default_backend
-from .ops import Kmeans
+from .ops import IndexFlatL2, Kmeans
 
 
 @dataclass
@@ -97,10 +97,12 @@ class DevicePipeline:
         sync(); secs["kmeans"] = time.perf_counter() - t0
 
         t0 = time.perf_counter()
-        tok_tr, _ = be.assign(frames_tr, centroids, want_dist=False)
+        index = IndexFlatL2(self.n_mels, backend=be)          # SpecTokenizer.load_centroid_index
+        index.add(centroids)
+        tok_tr, _ = index.assign(frames_tr, want_dist=False)  # index.search(x, 1), ids only
         tok_va = be.empty((0,), torch.int64)
         if frames_va is not None:
-            tok_va, _ = be.assign(frames_va, centroids, want_dist=False)
+            tok_va, _ = index.assign(frames_va, want_dist=False)
         sync(); secs["tokenize"] = time.perf_counter() - t0
 
         return PipelineResult(centroids, tok_tr, tok_va, T, secs, stats)

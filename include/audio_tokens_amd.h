@@ -123,18 +123,26 @@ int at_assign_hinted_f32(at_ctx* ctx, const float* x, int64_t n, int d, const fl
  *   centroid p to the nearest member of group g (groups of 32 as listed in cperm, DEVICE int32).
  * at_visit_order_f32: rows sorted by (previous id, previous distance): order_out and the ids in
  *   that order (both DEVICE uint32 [n]).
- * at_assign_pruned_f32: the answer of at_assign_f32, bit for bit (d = 64 or 128, n >= 20,
+ * at_group_means_f32: means[g] (DEVICE float [ng][d]) = mean row of group g.
+ * at_assign_pruned_f32, mode 0: the answer of at_assign_f32, bit for bit (d = 64 or 128, n >= 20,
  *   ng <= 512).  Every row's guess hint_sorted[p] (for row order[p]) is scored exactly first; a
  *   32-centroid group is then skipped for a 32-row tile when the triangle inequality, with a margin
- *   that covers the fp32 rounding of the distances, rules it out for all of the tile's rows. */
+ *   that covers the fp32 rounding of the distances, rules it out for all of the tile's rows.
+ *   mode 1 (a guess generator, NOT exact): hint_sorted holds a GROUP id per row; each row gets the
+ *   best centroid among the groups named by its 32-row tile; dmin_or_null is then read as an
+ *   optional uint32 [ng][ceil(ng/32)] table: bit set = group worth searching for a row naming g.  The unguided exact search is
+ *   nearest group mean -> mode 1 -> mode 0 with the mode-1 answers as guesses. */
 int at_group_rows_kd_host(const float* rows_host, int k, int d, int leaf, int32_t* perm_out_host);
 int at_group_min_dist_f32(at_ctx* ctx, const float* c, int k, int d, const int32_t* cperm, int ng,
                           float* dmin, void* stream);
 int at_visit_order_f32(at_ctx* ctx, const int64_t* ids, const float* dis_or_null, int64_t n, int k,
                        uint32_t* order_out, uint32_t* hint_sorted_out, void* stream);
+int at_group_means_f32(at_ctx* ctx, const float* c, int k, int d, const int32_t* cperm, int ng,
+                       float* means, void* stream);
 int at_assign_pruned_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
                          const uint32_t* order, const uint32_t* hint_sorted, const int32_t* cperm,
-                         int ng, const float* dmin, int64_t* ids, float* dist_or_null, void* stream);
+                         int ng, const float* dmin_or_null, int mode, int64_t* ids, float* dist_or_null,
+                         void* stream);
 
 /* out[i] = x[idx[i]] (rows of d floats).  idx: DEVICE int32 [m]. */
 int at_gather_rows_f32(at_ctx* ctx, const float* x, int d, const int32_t* idx, int64_t m,

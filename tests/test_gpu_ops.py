@@ -112,6 +112,9 @@ def test_assign_pruned_is_exact(be, oracle, n, d, k):
         ids, dis = be.assign_pruned(xt, ct, order, cperm, dmin)
         assert np.array_equal(ids.cpu().numpy(), ids_o), f"hint={name}: {(ids.cpu().numpy() != ids_o).sum()} ids differ"
         assert np.array_equal(bits(dis.cpu().numpy()), bits(dis_o)), name
+    # unguided coarse-to-fine search: same answer again
+    ids, dis = be.assign_c2f(xt, ct, cperm, dmin)
+    assert np.array_equal(ids.cpu().numpy(), ids_o) and np.array_equal(bits(dis.cpu().numpy()), bits(dis_o))
     # the visiting order is a permutation sorted by guess
     order, hs = be.visit_order(truth, dtruth, k)
     o = order.cpu().numpy().view(np.uint32).astype(np.int64)

@@ -13,7 +13,7 @@ wave = synth_clips(clips, device="cuda")
 frames = be.logmel(wave, frame_major=True, l2norm=True)
 del wave
 print("frames", tuple(frames.shape), flush=True)
-for rep in range(2):
+for rep in range(3):
     km = Kmeans(64, k, niter=20, backend=be)
     km.phase_seconds = {}
     t0 = time.perf_counter(); km.train(frames); torch.cuda.synchronize(); t1 = time.perf_counter()
