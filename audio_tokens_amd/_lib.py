@@ -37,6 +37,7 @@ SIGNATURES = {
     "at_group_rows_kd_host": (_i32, [_vp, _i32, _i32, _i32, _vp]),
     "at_group_min_dist_f32": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "at_visit_order_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "at_prune_stats": (_i32, [_vp, _c.POINTER(_i64), _c.POINTER(_i64), _i32]),
     "at_group_means_f32": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "at_assign_pruned_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
     "at_gather_rows_f32": (_i32, [_vp, _vp, _i32, _vp, _i64, _vp, _vp]),

@@ -230,6 +230,13 @@ class HipBackend(HostHelpers):
                                                    self._stream()))
         return order, hs
 
+    def prune_stats(self, reset=False):
+        """(accumulators computed, accumulators of the dense sweep) over this context's exact pruned
+        sweeps so far.  Synchronises."""
+        a, t = ctypes.c_int64(0), ctypes.c_int64(0)
+        _lib.check(self.lib.at_prune_stats(self.ctx.handle, ctypes.byref(a), ctypes.byref(t), 1 if reset else 0))
+        return int(a.value), int(t.value)
+
     def group_means(self, c, cperm) -> torch.Tensor:
         c = self._f32(c)
         k, d = c.shape

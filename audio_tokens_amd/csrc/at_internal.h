@@ -21,6 +21,7 @@ enum at_ws_slot {
     WS_LOGMEL_FB,      // log-mel: banded filterbank tables
     WS_PRUNE_BD,       // pruned sweep: exact distance to the guess, per visiting position
     WS_PRUNE_MASK,     // pruned sweep: per 32-row tile, one bit per 32-centroid group
+    WS_PRUNE_STATS,    // pruned sweep: {accumulators computed, accumulators of the dense sweep}
     WS_NSLOTS
 };
 

@@ -116,7 +116,8 @@ __global__ void __launch_bounds__(WG) prune_mask_kernel(const float* __restrict_
                                                         const float* __restrict__ dmin, int ng,
                                                         const unsigned* __restrict__ cnmax_bits,
                                                         float* __restrict__ bd_out,
-                                                        uint32_t* __restrict__ mask, int ngw) {
+                                                        uint32_t* __restrict__ mask, int ngw,
+                                                        unsigned long long* __restrict__ stats) {
     const int lane = threadIdx.x & 63;
     const long wpos = ((long)blockIdx.x * (WG / 64) + (threadIdx.x >> 6)) * 64;
     if (wpos >= n) return;
@@ -152,6 +153,7 @@ __global__ void __launch_bounds__(WG) prune_mask_kernel(const float* __restrict_
     const float* drow = dmin + (size_t)(has ? p : 0) * ng;
     const long tile = wpos / 32;
     const bool second = wpos + 32 < n;
+    int needed = 0;
     for (int w = 0; w < ngw; w++) {
         uint32_t bitsA = 0, bitsB = 0;
         const int g1 = min(32, ng - 32 * w);
@@ -165,6 +167,12 @@ __global__ void __launch_bounds__(WG) prune_mask_kernel(const float* __restrict_
             mask[(size_t)tile * ngw + w] = bitsA;
             if (second) mask[(size_t)(tile + 1) * ngw + w] = bitsB;
         }
+        needed += __builtin_popcount(bitsA) + (second ? __builtin_popcount(bitsB) : 0);
+    }
+    if (lane == 0) {  // statistics only (256 slots to keep the atomics off one address)
+        unsigned long long* slot = stats + 2 * (blockIdx.x & 255);
+        atomicAdd(&slot[0], (unsigned long long)needed);
+        atomicAdd(&slot[1], (unsigned long long)ng * (second ? 2 : 1));
     }
 }
 
@@ -233,12 +241,16 @@ int at_prune_prepass(at_ctx* ctx, const float* x, int64_t n, int d, const float*
     AT_LAUNCH_CHECK();
     const long waves = (n + 63) / 64;
     const dim3 grid((unsigned)((waves + WG / 64 - 1) / (WG / 64)));
+    const bool fresh = ctx->ws[WS_PRUNE_STATS] == nullptr;
+    unsigned long long* stats = static_cast<unsigned long long*>(at_ws(ctx, WS_PRUNE_STATS, 4096, stream));
+    if (!stats) return AT_E_NOMEM;
+    if (fresh) AT_HIP(hipMemsetAsync(stats, 0, 4096, stream));
     if (d == 64)
         hipLaunchKernelGGL(prune_mask_kernel<64>, grid, dim3(WG), 0, stream, x, (long)n, c, k, order, hint_sorted,
-                           dmin, ng, cnmax, bd_out, mask, ngw);
+                           dmin, ng, cnmax, bd_out, mask, ngw, stats);
     else
         hipLaunchKernelGGL(prune_mask_kernel<128>, grid, dim3(WG), 0, stream, x, (long)n, c, k, order, hint_sorted,
-                           dmin, ng, cnmax, bd_out, mask, ngw);
+                           dmin, ng, cnmax, bd_out, mask, ngw, stats);
     AT_LAUNCH_CHECK();
     return AT_OK;
 }
@@ -257,6 +269,22 @@ int at_group_min_dist_f32(at_ctx* ctx, const float* c, int k, int d, const int32
     else
         hipLaunchKernelGGL(group_min_dist_kernel<128>, grid, dim3(WG), 0, stream, c, k, cperm, ng, dmin);
     AT_LAUNCH_CHECK();
+    return AT_OK;
+}
+
+int at_prune_stats(at_ctx* ctx, int64_t* needed, int64_t* total, int reset) {
+    AT_REQUIRE(ctx && needed && total, "at_prune_stats: bad arguments");
+    *needed = *total = 0;
+    if (!ctx->ws[WS_PRUNE_STATS]) return AT_OK;
+    AT_HIP(hipSetDevice(ctx->device));
+    unsigned long long host[512];
+    AT_HIP(hipDeviceSynchronize());
+    AT_HIP(hipMemcpy(host, ctx->ws[WS_PRUNE_STATS], sizeof host, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 256; i++) {
+        *needed += (int64_t)host[2 * i];
+        *total += (int64_t)host[2 * i + 1];
+    }
+    if (reset) AT_HIP(hipMemset(ctx->ws[WS_PRUNE_STATS], 0, 4096));
     return AT_OK;
 }
 

@@ -133,6 +133,9 @@ int at_assign_hinted_f32(at_ctx* ctx, const float* x, int64_t n, int d, const fl
  *   optional uint32 [ng][ceil(ng/32)] table: bit set = group worth searching for a row naming g.  The unguided exact search is
  *   nearest group mean -> mode 1 -> mode 0 with the mode-1 answers as guesses. */
 int at_group_rows_kd_host(const float* rows_host, int k, int d, int leaf, int32_t* perm_out_host);
+/* Running totals over the context's mode-0 pruned sweeps: 32x32 accumulators actually computed and
+ * accumulators a dense sweep would compute.  Synchronises the device; reset != 0 clears them. */
+int at_prune_stats(at_ctx* ctx, int64_t* needed_host, int64_t* total_host, int reset);
 int at_group_min_dist_f32(at_ctx* ctx, const float* c, int k, int d, const int32_t* cperm, int ng,
                           float* dmin, void* stream);
 int at_visit_order_f32(at_ctx* ctx, const int64_t* ids, const float* dis_or_null, int64_t n, int k,
