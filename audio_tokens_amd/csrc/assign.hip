@@ -684,6 +684,169 @@ assign_mfma_pruned_kernel(const float* __restrict__ X, long n, const float* __re
     }
 }
 
+// Register-staged form of the pruned sweep: the A fragments of the NEXT needed group are loaded
+// from the (L2-resident) image straight into registers while the current group's MFMAs run, so
+// there is no LDS, no DMA wait and no barrier at all; two register sets alternate (the loop body is
+// written out for both roles).
+template <int D, int NB>
+__global__ void __launch_bounds__(64, 2)
+assign_mfma_pruned_reg_kernel(const float* __restrict__ X, long n, const float* __restrict__ img, int ng,
+                              const uint32_t* __restrict__ order, const uint32_t* __restrict__ hint_sorted,
+                              const float* __restrict__ bd_in, const uint32_t* __restrict__ mask, int ngw,
+                              long* __restrict__ ids, float* __restrict__ dist) {
+    constexpr int GROUP_F = 32 * D + GROUP_PAD;
+    constexpr int NQ = D / 8;
+    constexpr int MAXW = 16;
+
+    const int lane = threadIdx.x;
+    const int j = lane & 31;
+    const int h = lane >> 5;
+    const long pos0 = (long)blockIdx.x * (32 * NB);
+    const long ntile32 = (n + 31) / 32;
+
+    float xr[NB][D / 2];
+    float xn[NB];
+    float bestd[NB];
+    unsigned besti[NB];
+    long rowid[NB];
+    uint32_t mw[NB][MAXW];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        long pos = pos0 + 32 * b + j;
+        if (pos >= n) pos = n - 1;
+        const long r = (long)order[pos];
+        rowid[b] = r;
+        const f32x4* p = reinterpret_cast<const f32x4*>(X + r * D);
+        float nrm = 0.0f;
+#pragma unroll
+        for (int q = 0; q < D / 8; q++) {
+            const f32x4 u = p[2 * q], v = p[2 * q + 1];
+#pragma unroll
+            for (int e = 0; e < 4; e++) nrm = __builtin_fmaf(u[e], u[e], nrm);
+#pragma unroll
+            for (int e = 0; e < 4; e++) nrm = __builtin_fmaf(v[e], v[e], nrm);
+            xr[b][4 * q + 0] = h ? u[1] : u[0];
+            xr[b][4 * q + 1] = h ? u[3] : u[2];
+            xr[b][4 * q + 2] = h ? v[1] : v[0];
+            xr[b][4 * q + 3] = h ? v[3] : v[2];
+        }
+        xn[b] = nrm;
+        bestd[b] = bd_in[pos];
+        besti[b] = bestd[b] < __builtin_inff() ? hint_sorted[pos] : 0xffffffffu;
+        const long tile = pos0 / 32 + b;
+#pragma unroll
+        for (int w = 0; w < MAXW; w++) {
+            uint32_t m = 0;
+            if (w < ngw && tile < ntile32) m = mask[(size_t)tile * ngw + w];
+            mw[b][w] = __builtin_amdgcn_readfirstlane(m);
+        }
+    }
+    uint32_t any[MAXW];
+#pragma unroll
+    for (int w = 0; w < MAXW; w++) {
+        any[w] = 0;
+#pragma unroll
+        for (int b = 0; b < NB; b++) any[w] |= mw[b][w];
+    }
+    auto word_of = [&](const uint32_t (&m)[MAXW], int w) -> uint32_t {
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < MAXW; i++)
+            if (i == w) v = m[i];
+        return v;
+    };
+    auto next_group = [&](int from) {
+        int w = from >> 5;
+        if (w >= ngw) return ng;
+        uint32_t bits = word_of(any, w) & (0xffffffffu << (from & 31));
+        while (bits == 0) {
+            if (++w >= ngw) return ng;
+            bits = word_of(any, w);
+        }
+        const int g = (w << 5) + __builtin_ctz(bits);
+        return g < ng ? g : ng;
+    };
+
+    const int swz = j & 15;
+    auto load_group = [&](int g, f32x4 (&av)[NQ], f32x4 (&cn)[4]) {
+        const float* base = img + (size_t)g * GROUP_F;
+        const float* arow = base + j * D;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) av[q] = *reinterpret_cast<const f32x4*>(arow + (((2 * q + h) ^ swz) << 2));
+#pragma unroll
+        for (int q = 0; q < 4; q++) cn[q] = *reinterpret_cast<const f32x4*>(base + 32 * D + 8 * q + 4 * h);
+    };
+    auto compute_group = [&](int g, const f32x4 (&av)[NQ], const f32x4 (&cnv)[4]) {
+        const uint32_t gbit = 1u << (g & 31);
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            if ((word_of(mw[b], g >> 5) & gbit) == 0u) continue;  // wave-uniform
+            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][0], xr[b][4 * q + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][1], xr[b][4 * q + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][2], xr[b][4 * q + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][3], xr[b][4 * q + 3], acc, 0, 0, 0);
+            }
+            float m = __builtin_inff();
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float d0 = __builtin_fmaf(-2.0f, acc[r], xn[b] + cnv[r >> 2][r & 3]);
+                const float d1 = __builtin_fmaf(-2.0f, acc[r + 1], xn[b] + cnv[(r + 1) >> 2][(r + 1) & 3]);
+                m = __builtin_fminf(__builtin_fminf(m, d0), d1);
+            }
+            if (__builtin_amdgcn_ballot_w64(m <= bestd[b]) != 0) {
+                const unsigned* idxrow =
+                    reinterpret_cast<const unsigned*>(img + (size_t)g * GROUP_F) + 32 * D + 128 + 4 * h;
+                float bd = bestd[b];
+                unsigned bi = besti[b];
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float dd = __builtin_fmaxf(__builtin_fmaf(-2.0f, acc[r], xn[b] + cnv[r >> 2][r & 3]), 0.0f);
+                    const unsigned idx = idxrow[(r & 3) + 8 * (r >> 2)];
+                    const bool better = dd < bd || (dd == bd && idx < bi);
+                    bd = better ? dd : bd;
+                    bi = better ? idx : bi;
+                }
+                bestd[b] = bd;
+                besti[b] = bi;
+            }
+        }
+    };
+
+    f32x4 avA[NQ], cnA[4], avB[NQ], cnB[4];
+    int g = next_group(0);
+    if (g < ng) load_group(g, avA, cnA);
+    while (g < ng) {
+        const int g1 = next_group(g + 1);
+        if (g1 < ng) load_group(g1, avB, cnB);
+        compute_group(g, avA, cnA);
+        if (g1 >= ng) break;
+        const int g2 = next_group(g1 + 1);
+        if (g2 < ng) load_group(g2, avA, cnA);
+        compute_group(g1, avB, cnB);
+        g = g2;
+    }
+
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const float od = __shfl_xor(bestd[b], 32);
+        const unsigned oi = (unsigned)__shfl_xor((int)besti[b], 32);
+        float fd = bestd[b];
+        unsigned fi = besti[b];
+        if (od < fd || (od == fd && oi < fi)) {
+            fd = od;
+            fi = oi;
+        }
+        const long pos = pos0 + 32 * b + j;
+        if (h == 0 && pos < n) {
+            ids[rowid[b]] = fi == 0xffffffffu ? -1L : (long)fi;
+            if (dist) dist[rowid[b]] = fd;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Any d that is a multiple of 4 (n_mels other than 64/128, use_convolution's d = 10*n_mels):
 // the same MFMA sweep with the feature axis cut into chunks of 64.  The NA*NB accumulators of a
@@ -1099,9 +1262,16 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
     if (rc) return rc;
     const size_t lds = 2 * sizeof(float) * tile_floats(D, 1);
     const int64_t rows_per_wg = 32 * NB;
-    hipLaunchKernelGGL((assign_mfma_pruned_kernel<D, NB>), dim3((unsigned)((n + rows_per_wg - 1) / rows_per_wg)),
-                       dim3(64), lds, stream, x, (long)n, img, ng, order, hint_sorted, bd, mask, ngw,
-                       reinterpret_cast<long*>(ids), dist);
+    // d = 64: register-staged A operand (no LDS); AT_PRUNE_KERNEL=0 selects the LDS-DMA form (A/B aid)
+    const char* ev = std::getenv("AT_PRUNE_KERNEL");
+    if (!(ev && std::atoi(ev) == 0) && D == 64 && NB <= 2)
+        hipLaunchKernelGGL((assign_mfma_pruned_reg_kernel<D, NB>), dim3((unsigned)((n + rows_per_wg - 1) / rows_per_wg)),
+                           dim3(64), 0, stream, x, (long)n, img, ng, order, hint_sorted, bd, mask, ngw,
+                           reinterpret_cast<long*>(ids), dist);
+    else
+        hipLaunchKernelGGL((assign_mfma_pruned_kernel<D, NB>), dim3((unsigned)((n + rows_per_wg - 1) / rows_per_wg)),
+                           dim3(64), lds, stream, x, (long)n, img, ng, order, hint_sorted, bd, mask, ngw,
+                           reinterpret_cast<long*>(ids), dist);
     AT_LAUNCH_CHECK();
     return AT_OK;
 }

@@ -213,56 +213,4 @@ int at_split_clusters_host(int d, int k, int64_t n, float* hassign, float* centr
 }
 
 
-// Balanced kd-style grouping of the centroid table (performance aid of the pruned Lloyd sweep; it
-// never affects results): recursively cut the rows at the median of their widest-spread feature
-// until a part holds at most `leaf` rows.  perm_out receives ceil(k/leaf)*leaf entries: the rows
-// group after group, each group padded to `leaf` entries with -1.
-int at_group_rows_kd_host(const float* rows, int k, int d, int leaf, int32_t* perm_out) {
-    AT_REQUIRE(rows && perm_out && k > 0 && d > 0 && leaf > 0, "at_group_rows_kd_host: bad arguments");
-    const int ngroups = (k + leaf - 1) / leaf;
-    std::vector<int32_t> idx((size_t)k);
-    for (int i = 0; i < k; i++) idx[i] = i;
-    // a part [lo, hi) destined to fill groups [g0, g1): cut so that the left side fills whole groups
-    struct Part { int lo, hi, g0, g1; };
-    std::vector<Part> stack{{0, k, 0, ngroups}};
-    std::vector<int> bounds((size_t)ngroups + 1, 0);
-    bounds[ngroups] = k;
-    std::vector<double> mean((size_t)d), var((size_t)d);
-    while (!stack.empty()) {
-        const Part p = stack.back();
-        stack.pop_back();
-        if (p.g1 - p.g0 <= 1) {
-            bounds[p.g0] = p.lo;
-            continue;
-        }
-        std::fill(mean.begin(), mean.end(), 0.0);
-        std::fill(var.begin(), var.end(), 0.0);
-        for (int i = p.lo; i < p.hi; i++)
-            for (int f = 0; f < d; f++) mean[f] += rows[(size_t)idx[i] * d + f];
-        for (int f = 0; f < d; f++) mean[f] /= (p.hi - p.lo);
-        for (int i = p.lo; i < p.hi; i++)
-            for (int f = 0; f < d; f++) {
-                const double t = rows[(size_t)idx[i] * d + f] - mean[f];
-                var[f] += t * t;
-            }
-        int dim = 0;
-        for (int f = 1; f < d; f++)
-            if (var[f] > var[dim]) dim = f;
-        const int gmid = p.g0 + (p.g1 - p.g0) / 2;
-        int cut = p.lo + (gmid - p.g0) * leaf;  // left side = whole groups
-        if (cut > p.hi) cut = p.hi;
-        std::nth_element(idx.begin() + p.lo, idx.begin() + cut, idx.begin() + p.hi, [&](int32_t a, int32_t b) {
-            const float va = rows[(size_t)a * d + dim], vb = rows[(size_t)b * d + dim];
-            return va < vb || (va == vb && a < b);
-        });
-        stack.push_back({p.lo, cut, p.g0, gmid});
-        stack.push_back({cut, p.hi, gmid, p.g1});
-    }
-    for (int g = 0; g < ngroups; g++) {
-        const int lo = bounds[g], hi = bounds[g + 1];
-        for (int e = 0; e < leaf; e++) perm_out[(size_t)g * leaf + e] = lo + e < hi ? idx[lo + e] : -1;
-    }
-    return AT_OK;
-}
-
 }  // extern "C"
