@@ -51,6 +51,15 @@ def _worker(rank, world, port, q):
             kc = Kmeans(8, 64, niter=5, distributed=True)
             kc.train(x[:cut] if rank == 0 else x[cut:], init_centroids=g["c_init"])
             out["sub"] = kc.centroids.copy()
+            # big enough for the exact pruned sweep (k >= 1024, >= 4096 rows per rank)
+            rng = np.random.default_rng(5)
+            cen = rng.standard_normal((1024, 64))
+            xb = (cen[rng.integers(0, 1024, 30000)] + 0.3 * rng.standard_normal((30000, 64))).astype(np.float32)
+            xb /= np.linalg.norm(xb, axis=1, keepdims=True)
+            kp = Kmeans(64, 1024, niter=6, distributed=True)
+            assert kp.prune
+            kp.train(xb[:14000] if rank == 0 else xb[14000:])
+            out["pruned"] = kp.centroids.copy()
             # whole device pipeline, 2 ranks x 3 clips
             wave = synth_clips(6, L=22050 * 2, seed=11, device="cuda")
             mine = wave[rank * 3:(rank + 1) * 3]
@@ -82,6 +91,14 @@ def test_two_ranks_one_gpu(oracle, be):
         warnings.simplefilter("ignore")
         r = oracle.kmeans_train(g["c_x"], 64, niter=5, init_centroids=g["c_init"], shard=shard, n_shards=2)
     assert np.array_equal(bits(res[0]["sub"]), bits(r.centroids)) and np.array_equal(bits(res[1]["sub"]), bits(r.centroids))
+    rng = np.random.default_rng(5)
+    cen = rng.standard_normal((1024, 64))
+    xb = (cen[rng.integers(0, 1024, 30000)] + 0.3 * rng.standard_normal((30000, 64))).astype(np.float32)
+    xb /= np.linalg.norm(xb, axis=1, keepdims=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rp = oracle.kmeans_train(xb, 1024, niter=6, shard=(np.arange(30000) >= 14000).astype(np.int32), n_shards=2)
+    assert np.array_equal(bits(res[0]["pruned"]), bits(rp.centroids)) and np.array_equal(bits(res[1]["pruned"]), bits(rp.centroids))
     # pipeline: both ranks hold the same centroids; the oracle reproduces them from the same frames
     assert np.array_equal(bits(res[0]["pipe_centroids"]), bits(res[1]["pipe_centroids"]))
     from audio_tokens_amd.synth import synth_clips

@@ -73,6 +73,47 @@ def test_logmel_spectrogram_operator(be):
     assert np.array_equal(bits(allc[0].cpu().numpy()), bits(one[0].cpu().numpy()))
 
 
+def test_kmeans_pruned_path_matches_oracle(be, oracle):
+    """A train() large enough to take the pruned / coarse-to-fine path (k >= 1024), cold start and
+    warm start, against the oracle; and the same with pruning switched off."""
+    from audio_tokens_amd.ops import Kmeans
+    rng = np.random.default_rng(9)
+    cen = rng.standard_normal((2048, 64))
+    x = (cen[rng.integers(0, 2048, 60000)] + 0.4 * rng.standard_normal((60000, 64))).astype(np.float32)
+    x = oracle.l2norm_rows(x)
+    x[:300] = x[300:600]                                    # duplicates
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r1 = oracle.kmeans_train(x[:40000], 2048, niter=8)
+        r2 = oracle.kmeans_train(x[40000:], 2048, niter=8, init_centroids=r1.centroids)
+        for prune in (True, False):
+            km = Kmeans(64, 2048, niter=8)
+            km.prune = prune
+            km.train(x[:40000])
+            assert np.array_equal(bits(km.centroids), bits(r1.centroids)), f"prune={prune} cold"
+            assert [s["nsplit"] for s in km.iteration_stats] == list(r1.nsplit)
+            km.train(x[40000:], init_centroids=km.centroids)
+            assert np.array_equal(bits(km.centroids), bits(r2.centroids)), f"prune={prune} warm"
+    a, t = be.prune_stats()
+    assert 0 < a < t                                         # something was really skipped
+
+
+def test_index_flat_l2_large_search_uses_exact_pruning(be, oracle):
+    from audio_tokens_amd.ops import IndexFlatL2
+    rng = np.random.default_rng(10)
+    c = oracle.l2norm_rows(rng.standard_normal((4096, 64)).astype(np.float32))
+    x = oracle.l2norm_rows((c[rng.integers(0, 4096, 100000)] + 0.05 * rng.standard_normal((100000, 64))).astype(np.float32))
+    ids_o, dis_o = oracle.assign(x, c)
+    index = IndexFlatL2(64)
+    index.add(c)
+    D, I = index.search(x, 1)
+    assert index._prune is not None
+    assert np.array_equal(I[:, 0], ids_o) and np.array_equal(bits(D[:, 0]), bits(dis_o))
+    index.prune = False
+    D2, I2 = index.search(x, 1)
+    assert np.array_equal(I2, I) and np.array_equal(bits(D2), bits(D))
+
+
 def test_full_size_properties(be):
     """BASELINE-size launch (2 097 152 x 64 vs 8192): size-independent checks."""
     gen = torch.Generator(device="cuda").manual_seed(1)

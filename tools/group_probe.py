@@ -68,3 +68,24 @@ for name, ordc in (("axis kd (product)", torch.from_numpy(be.group_rows_kd(be.to
         nd = (dmin[p[s:e]] <= tau[s:e, None]).view(-1, 32, dmin.shape[1]).any(1)
         tot += nd.float().sum().item(); cnt += nd.numel()
     print(f"{name}: accumulators needed {100*tot/cnt:.1f}%")
+
+# ---- would a second, row-centred bound help?  |x - c| >= |x - m_g| - rad_g
+ordc = torch.from_numpy(be.group_rows_kd(be.to_host(C1)).astype(np.int64)).cuda()
+cperm = ordc.int().contiguous()
+dmin = be.group_min_dist(C1, cperm)
+G = C1[ordc].view(-1, 32, 64)
+mg = G.mean(1)
+rad = ((G - mg[:, None, :]) ** 2).sum(2).sqrt().max(1).values
+xo = xs[o]
+R = (dnew + 1.6e-5).sqrt()
+tot1 = tot2 = cnt = 0
+step = 2048 * 32
+for s in range(0, n32, step):
+    e = min(n32, s + step)
+    n1 = dmin[p[s:e]] <= tau[s:e, None]
+    dg = torch.cdist(xo[s:e], mg)
+    n2 = n1 & ((dg - rad[None, :]) <= R[s:e, None] * 1.0001 + 1e-4)
+    tot1 += n1.view(-1, 32, n1.shape[1]).any(1).float().sum().item()
+    tot2 += n2.view(-1, 32, n2.shape[1]).any(1).float().sum().item()
+    cnt += n1.numel() // 32
+print(f"centroid bound only: {100*tot1/cnt:.1f}%   with the row-centred group bound too: {100*tot2/cnt:.1f}%")
