@@ -39,7 +39,8 @@ SIGNATURES = {
     "at_visit_order_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "at_prune_stats": (_i32, [_vp, _c.POINTER(_i64), _c.POINTER(_i64), _i32]),
     "at_group_means_f32": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
-    "at_assign_pruned_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
+    "at_assign_pruned_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "at_prune_mask_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp]),
     "at_gather_rows_f32": (_i32, [_vp, _vp, _i32, _vp, _i64, _vp, _vp]),
     "at_centroid_accum_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "at_centroid_finalize_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),

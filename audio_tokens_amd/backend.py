@@ -286,12 +286,15 @@ class HipBackend(HostHelpers):
         ids = self.empty((n,), torch.int64)
         dist = self.empty((n,), torch.float32) if (want_dist or mode == 1) else None
         rec = self.assign_trace
-        if rec is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(torch.cuda.current_stream(self.device))
         with torch.cuda.device(self.device):
+            # pre-pass (bound + masks) first, so that the events below bracket the sweep kernel only
+            _lib.check(self.lib.at_prune_mask_f32(self.ctx.handle, _ptr(x), n, d, _ptr(c), k, _ptr(order),
+                                                  _ptr(hint_sorted), ng, _ptr(dmin), mode, self._stream()))
+            if rec is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(torch.cuda.current_stream(self.device))
             _lib.check(self.lib.at_assign_pruned_f32(self.ctx.handle, _ptr(x), n, d, _ptr(c), k, _ptr(order),
-                                                     _ptr(hint_sorted), _ptr(cperm), ng, _ptr(dmin), mode, _ptr(ids),
+                                                     _ptr(hint_sorted), _ptr(cperm), ng, _ptr(dmin), mode, 1, _ptr(ids),
                                                      _ptr(dist), self._stream()))
         if rec is not None:
             e1.record(torch.cuda.current_stream(self.device))

@@ -1246,7 +1246,7 @@ int at_prune_prepass(at_ctx* ctx, const float* x, int64_t n, int d, const float*
 template <int D, int NB>
 static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c, int k, const uint32_t* order,
                          const uint32_t* hint_sorted, const int32_t* cperm, int ng, const float* dmin, int mode,
-                         int64_t* ids, float* dist, hipStream_t stream) {
+                         bool prepass_done, int64_t* ids, float* dist, hipStream_t stream) {
     const int kp = ng * 32;
     const int ngw = (ng + 31) / 32;
     const size_t img_bytes = sizeof(float) * (size_t)ng * tile_floats(D, 1);
@@ -1258,8 +1258,10 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
     // image: one tile per group (NA = 1): 32 rows, then |c|^2 at [0,32) and indices at [128,160)
     hipLaunchKernelGGL(prep_centroids_perm_kernel, dim3(ng), dim3(WG), 0, stream, c, k, D, cperm, kp, 1, img);
     AT_LAUNCH_CHECK();
-    int rc = at_prune_prepass(ctx, x, n, D, c, k, order, hint_sorted, dmin, ng, bd, mask, ngw, mode, stream);
-    if (rc) return rc;
+    if (!prepass_done) {
+        int rc = at_prune_prepass(ctx, x, n, D, c, k, order, hint_sorted, dmin, ng, bd, mask, ngw, mode, stream);
+        if (rc) return rc;
+    }
     const size_t lds = 2 * sizeof(float) * tile_floats(D, 1);
     const int64_t rows_per_wg = 32 * NB;
     // d = 64: register-staged A operand (no LDS); AT_PRUNE_KERNEL=0 selects the LDS-DMA form (A/B aid)
@@ -1278,8 +1280,8 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
 
 extern "C" int at_assign_pruned_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
                                     const uint32_t* order, const uint32_t* hint_sorted, const int32_t* cperm,
-                                    int ng, const float* dmin, int mode, int64_t* ids, float* dist,
-                                    void* stream_) {
+                                    int ng, const float* dmin, int mode, int prepass_done, int64_t* ids,
+                                    float* dist, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     AT_REQUIRE(ctx, "at_assign_pruned_f32: ctx is null");
     AT_REQUIRE(x && c && order && hint_sorted && cperm && (dmin || mode == 1) && ids, "at_assign_pruned_f32: null pointer");
@@ -1291,9 +1293,28 @@ extern "C" int at_assign_pruned_f32(at_ctx* ctx, const float* x, int64_t n, int 
     AT_HIP(hipSetDevice(ctx->device));
     if (d == 64) {
         const char* e = std::getenv("AT_PRUNE_NB");
-        if (e && std::atoi(e) == 4) return launch_pruned<64, 4>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, ids, dist, stream);
-        if (e && std::atoi(e) == 1) return launch_pruned<64, 1>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, ids, dist, stream);
-        return launch_pruned<64, 2>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, ids, dist, stream);
+        if (e && std::atoi(e) == 4) return launch_pruned<64, 4>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, prepass_done != 0, ids, dist, stream);
+        if (e && std::atoi(e) == 1) return launch_pruned<64, 1>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, prepass_done != 0, ids, dist, stream);
+        return launch_pruned<64, 2>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, prepass_done != 0, ids, dist, stream);
     }
-    return launch_pruned<128, 2>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, ids, dist, stream);
+    return launch_pruned<128, 2>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, prepass_done != 0, ids, dist, stream);
+}
+
+// The pre-pass of at_assign_pruned_f32 on its own (per-row bound + per-tile group masks, kept in the
+// context's workspace): lets a caller time or overlap it separately, then call
+// at_assign_pruned_f32(..., prepass_done = 1) with the same arguments.
+extern "C" int at_prune_mask_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
+                                 const uint32_t* order, const uint32_t* hint_sorted, int ng, const float* dmin,
+                                 int mode, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AT_REQUIRE(ctx && x && c && order && hint_sorted && (dmin || mode == 1), "at_prune_mask_f32: null pointer");
+    AT_REQUIRE((d == 64 || d == 128) && n >= 20 && n < (int64_t)UINT32_MAX && ng > 0 && ng <= 512 && ng * 32 >= k,
+               "at_prune_mask_f32: bad sizes");
+    AT_HIP(hipSetDevice(ctx->device));
+    const int ngw = (ng + 31) / 32;
+    const int64_t ntile32 = (n + 31) / 32;
+    float* bd = static_cast<float*>(at_ws(ctx, WS_PRUNE_BD, sizeof(float) * (size_t)n, stream));
+    uint32_t* mask = static_cast<uint32_t*>(at_ws(ctx, WS_PRUNE_MASK, sizeof(uint32_t) * (size_t)ntile32 * ngw, stream));
+    if (!bd || !mask) return AT_E_NOMEM;
+    return at_prune_prepass(ctx, x, n, d, c, k, order, hint_sorted, dmin, ng, bd, mask, ngw, mode, stream);
 }

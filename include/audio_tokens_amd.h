@@ -144,8 +144,14 @@ int at_group_means_f32(at_ctx* ctx, const float* c, int k, int d, const int32_t*
                        float* means, void* stream);
 int at_assign_pruned_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
                          const uint32_t* order, const uint32_t* hint_sorted, const int32_t* cperm,
-                         int ng, const float* dmin_or_null, int mode, int64_t* ids, float* dist_or_null,
-                         void* stream);
+                         int ng, const float* dmin_or_null, int mode, int prepass_done, int64_t* ids,
+                         float* dist_or_null, void* stream);
+/* The pre-pass of at_assign_pruned_f32 alone (per-row bound and per-tile group masks into the
+ * context's workspace).  at_assign_pruned_f32 runs it itself unless prepass_done != 0, in which case
+ * it must directly follow this call with the same arguments on the same stream. */
+int at_prune_mask_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
+                      const uint32_t* order, const uint32_t* hint_sorted, int ng,
+                      const float* dmin_or_null, int mode, void* stream);
 
 /* out[i] = x[idx[i]] (rows of d floats).  idx: DEVICE int32 [m]. */
 int at_gather_rows_f32(at_ctx* ctx, const float* x, int d, const int32_t* idx, int64_t m,
