@@ -87,13 +87,22 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (no CPU fallback)"
+    # Rehearsal switches (not used by the driver): AT_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # AT_BENCH_BACKEND=gloo exchanges through the host, so the N > 1 code path can be exercised on a
+    # one-GPU box.  The real multi-GPU run is one rank per GPU over RCCL ("nccl").
+    if os.environ.get("AT_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("AT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from audio_tokens_amd.backend import default_backend
     from audio_tokens_amd.pipeline import DevicePipeline
@@ -133,7 +142,7 @@ def main():
     stage = pipe.run(wave_tr, wave_va, timing=True).stage_seconds  # one extra, untimed, per-stage split
 
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

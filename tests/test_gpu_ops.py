@@ -76,11 +76,14 @@ def test_assign_hinted_is_hint_independent(be, oracle, n, d, k):
     assert np.array_equal(sorted_ids.cpu().numpy().view(np.uint32), ids_o[ref_order].astype(np.uint32))
 
 
-@pytest.mark.parametrize("n,d,k", [(6000, 64, 300), (70000, 64, 8192), (3000, 128, 1000), (50000, 128, 4096),
-                                   (20000, 64, 2048)])
-def test_assign_pruned_is_exact(be, oracle, n, d, k):
+@pytest.mark.parametrize("n,d,k,lds_kernel", [(6000, 64, 300, False), (70000, 64, 8192, False), (3000, 128, 1000, False),
+                                              (50000, 128, 4096, False), (20000, 64, 2048, False),
+                                              (33333, 128, 1500, False), (33333, 64, 1500, True), (25001, 64, 16384, False)])
+def test_assign_pruned_is_exact(be, oracle, monkeypatch, n, d, k, lds_kernel):
     """at_assign_pruned_f32 == brute force, bit for bit, for good guesses (where it prunes), bad
     guesses, missing guesses and exact ties."""
+    if lds_kernel:
+        monkeypatch.setenv("AT_PRUNE_KERNEL", "0")   # the LDS-DMA form of the d=64 kernel
     rng = np.random.default_rng(n * 3 + d + k)
     # clustered data so that pruning actually happens
     centers = _unit_rows(rng, k, d, oracle)
