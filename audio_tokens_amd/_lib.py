@@ -31,6 +31,9 @@ SIGNATURES = {
     "at_num_frames": (_i64, [_i64, _i32]),
     "at_split_clusters_host": (_i32, [_i32, _i32, _i64, _vp, _vp, _c.POINTER(_i32)]),
     "at_logmel_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),
+    "at_resample_length": (_i64, [_i64, _i32, _i32]),
+    "at_resample_taps_host": (_i32, [_i32, _i32, _c.POINTER(_i32), _c.POINTER(_i32), _c.POINTER(_i32), _vp, _i64]),
+    "at_resample_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),
     "at_l2norm_rows_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "at_assign_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp]),
     "at_assign_hinted_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -58,6 +58,19 @@ class HostHelpers:
         _lib.check(self.lib.at_group_rows_kd_host(_np_ptr(rows), k, d, leaf, _np_ptr(out)))
         return out
 
+    def resample_taps(self, orig_freq: int, new_freq: int):
+        """-> (taps float32 [new, 2*width + orig], orig, new, width): torchaudio's sinc_interp_hann kernel."""
+        o, nw, w = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(self.lib.at_resample_taps_host(orig_freq, new_freq, ctypes.byref(o), ctypes.byref(nw),
+                                                  ctypes.byref(w), None, 0))
+        taps = np.empty((nw.value, 2 * w.value + o.value), np.float32)
+        _lib.check(self.lib.at_resample_taps_host(orig_freq, new_freq, ctypes.byref(o), ctypes.byref(nw),
+                                                  ctypes.byref(w), _np_ptr(taps), taps.size))
+        return taps, o.value, nw.value, w.value
+
+    def resample_length(self, L: int, orig_freq: int, new_freq: int) -> int:
+        return int(self.lib.at_resample_length(L, orig_freq, new_freq))
+
     def split_clusters(self, hassign: np.ndarray, centroids: np.ndarray, n: int) -> int:
         """In place on two C-contiguous float32 host arrays; returns nsplit."""
         assert hassign.dtype == np.float32 and centroids.dtype == np.float32
@@ -147,6 +160,22 @@ class HipBackend(HostHelpers):
                 _ptr(fbt), _ptr(out), _lib.AT_LAYOUT_FRAME_MAJOR if frame_major else _lib.AT_LAYOUT_MEL_MAJOR,
                 1 if l2norm else 0, self._stream()))
         return out
+
+    def resample(self, wave, orig_freq: int, new_freq: int) -> torch.Tensor:
+        """wave [n_clips, L] (or [L]) -> [n_clips, ceil(L*new/orig)] (torchaudio Resample defaults)."""
+        wave = self._f32(wave)
+        squeeze = wave.dim() == 1
+        if squeeze:
+            wave = wave.unsqueeze(0)
+        n_clips, L = wave.shape
+        out_len = self.resample_length(L, orig_freq, new_freq)
+        out = self.empty((n_clips, out_len))
+        with torch.cuda.device(self.device):
+            for c0 in range(0, n_clips, 65535):
+                c1 = min(n_clips, c0 + 65535)
+                _lib.check(self.lib.at_resample_f32(self.ctx.handle, _ptr(wave[c0:c1]), c1 - c0, L, wave.stride(0),
+                                                    orig_freq, new_freq, _ptr(out[c0:c1]), out.stride(0), self._stream()))
+        return out[0] if squeeze else out
 
     def l2norm_rows(self, x, out=None) -> torch.Tensor:
         x = self._f32(x)

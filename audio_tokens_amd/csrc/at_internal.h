@@ -22,6 +22,7 @@ enum at_ws_slot {
     WS_PRUNE_BD,       // pruned sweep: exact distance to the guess, per visiting position
     WS_PRUNE_MASK,     // pruned sweep: per 32-row tile, one bit per 32-centroid group
     WS_PRUNE_STATS,    // pruned sweep: {accumulators computed, accumulators of the dense sweep}
+    WS_RESAMPLE_TAPS,  // resampler: polyphase filter taps [new][2*width + orig]
     WS_NSLOTS
 };
 
@@ -32,6 +33,7 @@ struct at_ctx {
     // cached description of what WS_LOGMEL_FB currently holds
     int fb_sr, fb_nfft, fb_nmels, fb_nw;
     const float* fb_user;
+    int rs_orig, rs_new;  // what WS_RESAMPLE_TAPS currently holds
 };
 
 int at_fail(int code, const char* fmt, ...);

@@ -97,6 +97,7 @@ void* at_ws(at_ctx* ctx, int slot, size_t bytes, hipStream_t stream) {
     ctx->ws[slot] = p;
     ctx->ws_bytes[slot] = want;
     if (slot == WS_LOGMEL_FB) { ctx->fb_sr = ctx->fb_nfft = ctx->fb_nmels = 0; ctx->fb_user = nullptr; }
+    if (slot == WS_RESAMPLE_TAPS) ctx->rs_orig = ctx->rs_new = 0;
     return p;
 }
 

@@ -2,6 +2,8 @@
 
     torchaudio.transforms.MelSpectrogram + AmplitudeToDB  ->  LogMelSpectrogram
         (processors/spectrogram_generator.py:28-34,123-126 of danavery/audio-tokens)
+    torchaudio.transforms.Resample                        ->  Resample
+        (processors/spectrogram_generator.py:117-121)
     faiss.Kmeans                                          ->  Kmeans
         (processors/cluster_creator.py:42-56)
     faiss.IndexFlatL2                                     ->  IndexFlatL2
@@ -25,7 +27,7 @@ import torch
 
 from .backend import default_backend
 
-__all__ = ["LogMelSpectrogram", "Kmeans", "IndexFlatL2", "normalize_rows"]
+__all__ = ["LogMelSpectrogram", "Resample", "Kmeans", "IndexFlatL2", "normalize_rows"]
 
 
 def _is_host(x) -> bool:
@@ -68,6 +70,32 @@ class LogMelSpectrogram:
         be = self.backend
         return be.logmel(be._f32(waveform), self.sample_rate, self.n_fft, self.hop_length, self.n_mels,
                          fb=self.fb, frame_major=True, l2norm=l2norm)
+
+
+class Resample:
+    """torchaudio.transforms.Resample(orig_freq, new_freq) with its defaults (sinc_interp_hann,
+    lowpass_filter_width 6, rolloff 0.99).  __call__(waveform [..., L]) -> [..., ceil(L*new/orig)]
+    on the device; equal rates return the input unchanged, as torchaudio does."""
+
+    def __init__(self, orig_freq=16000, new_freq=16000, backend=None):
+        if int(orig_freq) != orig_freq or int(new_freq) != new_freq:
+            raise ValueError("Frequencies must be of integer type to ensure quality resampling computation.")
+        self.orig_freq, self.new_freq = int(orig_freq), int(new_freq)
+        if self.orig_freq <= 0 or self.new_freq <= 0:
+            raise ValueError("Original frequency and desired frequecy should be positive")
+        self.backend = backend or default_backend()
+
+    def to(self, device):
+        return self
+
+    def __call__(self, waveform):
+        if self.orig_freq == self.new_freq:
+            return waveform
+        be = self.backend
+        w = be._f32(waveform)
+        lead = w.shape[:-1]
+        out = be.resample(w.reshape(-1, w.shape[-1]), self.orig_freq, self.new_freq)
+        return out.reshape(*lead, out.shape[-1])
 
 
 class _Dist:

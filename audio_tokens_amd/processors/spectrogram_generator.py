@@ -6,6 +6,7 @@ Same constructor, methods, outputs (spectrograms/{train,validation}/<ytid>.npy, 
   * clips of one batch are decoded on the host, stacked by length and pushed through ONE fused
     STFT -> mel -> dB launch per length (the reference launches a dozen kernels per clip);
   * the whole batch comes back in one device->host copy before the per-file np.save.
+  * clips at another sample rate go through the device polyphase resampler (ops.Resample).
 Audio decoding stays on the CPU: torchaudio.load if torchaudio is importable, otherwise PCM/float
 .wav through the standard library and raw float32 .npy waveforms (used by the synthetic tests).
 """
@@ -21,7 +22,7 @@ import torch
 from tqdm import tqdm
 
 from ..audio_tokens_config import AudioTokensConfig
-from ..ops import LogMelSpectrogram
+from ..ops import LogMelSpectrogram, Resample
 
 try:  # optional: only used for decoding when it exists
     import torchaudio as _torchaudio
@@ -123,7 +124,7 @@ class SpectrogramGenerator:
             if L <= self.config.n_fft // 2:
                 self.logger.debug(f"clips shorter than the reflect padding skipped: {len(js)}")
                 continue
-            batch = torch.stack([waves[j].reshape(-1) for j in js])
+            batch = torch.stack([waves[j].reshape(-1).to(self.device) for j in js])
             out = self.spec_transformer(batch)                       # [B, n_mels, T] on the GPU
             if self.config.normalize:
                 out = torch.stack([self.normalize_spectrogram(s) for s in out])
@@ -170,12 +171,10 @@ class SpectrogramGenerator:
         return waveform
 
     def resample(self, waveform, sr):
+        """torchaudio.transforms.Resample(sr, common_sr)(waveform) on the device kernel; the taps of
+        the last rate pair stay resident, so a dataset at one native rate builds them once."""
         if sr != self.config.common_sr:
-            if _torchaudio is None:
-                raise NotImplementedError(
-                    f"clip at {sr} Hz: resampling to {self.config.common_sr} Hz needs torchaudio's "
-                    "Resample (SURVEY.md section 8f row 2: not part of the accelerated path yet)")
-            waveform = _torchaudio.transforms.Resample(sr, self.config.common_sr)(waveform)
+            waveform = Resample(sr, self.config.common_sr, backend=self.spec_transformer.backend)(waveform)
         return waveform
 
     def generate_mel_spectrogram(self, audio):

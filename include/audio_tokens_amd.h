@@ -8,6 +8,8 @@
  *
  *   torchaudio.transforms.MelSpectrogram(...)(wave) -> AmplitudeToDB()      at_logmel_f32
  *       processors/spectrogram_generator.py:28-34, 123-126
+ *   torchaudio.transforms.Resample(sr, 22050)(wave)                        at_resample_f32
+ *       processors/spectrogram_generator.py:117-121
  *   np.linalg.norm(axis=1) row normalisation                               at_l2norm_rows_f32
  *       processors/cluster_creator.py:64-66, processors/spec_tokenizer.py:106-109
  *   faiss.IndexFlatL2(d).add(c); .search(x, 1)                             at_assign_f32
@@ -91,6 +93,17 @@ int at_split_clusters_host(int d, int k, int64_t n, float* hassign_host, float* 
 int at_logmel_f32(at_ctx* ctx, const float* wave, int64_t n_clips, int64_t L, int64_t wave_stride,
                   int sample_rate, int n_fft, int hop, int n_mels, const float* fb_or_null,
                   float* out, int layout, int fuse_l2norm, void* stream);
+
+/* torchaudio.transforms.Resample(orig_freq, new_freq) with its defaults (sinc_interp_hann,
+ * lowpass_filter_width 6, rolloff 0.99) -- processors/spectrogram_generator.py:117-121.
+ * out: n_clips rows of at_resample_length(L, ...) samples, row stride out_stride floats.
+ * at_resample_taps_host builds the polyphase taps [new][2*width + orig] on the host (pass
+ * taps_host = NULL to query orig/new/width only). */
+int64_t at_resample_length(int64_t L, int orig_freq, int new_freq);
+int at_resample_taps_host(int orig_freq, int new_freq, int* orig_out, int* new_out, int* width_out,
+                          float* taps_host, int64_t taps_capacity);
+int at_resample_f32(at_ctx* ctx, const float* wave, int64_t n_clips, int64_t L, int64_t wave_stride,
+                    int orig_freq, int new_freq, float* out, int64_t out_stride, void* stream);
 
 /* y[i] = x[i] / (||x[i]||_2 + 1e-10), fp32, numpy's pairwise summation order (bit-exact with
  * numpy for finite inputs).  x == y is allowed. */

@@ -47,6 +47,10 @@ def _lib():
         L.orc_logmel.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                  ctypes.c_int, _f32p, _f32p]
         L.orc_logmel.restype = ctypes.c_int
+        L.orc_resample_length.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int]
+        L.orc_resample_length.restype = ctypes.c_int64
+        L.orc_resample.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _f32p]
+        L.orc_resample.restype = ctypes.c_int
         for fn in (L.orc_assign, L.orc_assign_ref):
             fn.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int, _f32p, ctypes.c_int, _i64p, _f32p]
         L.orc_split_clusters.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64, _f32p, _f32p]
@@ -142,6 +146,17 @@ def logmel(wave, sample_rate=22050, n_fft=512, hop=128, n_mels=64, fb=None) -> n
                            _p(out, _f32p))
     if rc != 0:
         raise ValueError("orc_logmel: bad arguments")
+    return out
+
+
+def resample(wave, orig_freq: int, new_freq: int) -> np.ndarray:
+    """torchaudio.transforms.Resample(orig_freq, new_freq)(wave) for one clip: [L] -> [ceil(L*new/orig)]."""
+    wave = _f32(wave).reshape(-1)
+    if orig_freq == new_freq:
+        return wave.copy()
+    out = np.empty(int(_lib().orc_resample_length(wave.shape[0], orig_freq, new_freq)), np.float32)
+    if _lib().orc_resample(_p(wave, _f32p), wave.shape[0], orig_freq, new_freq, _p(out, _f32p)) != 0:
+        raise ValueError("orc_resample: bad arguments")
     return out
 
 

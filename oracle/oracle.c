@@ -527,3 +527,61 @@ int orc_num_threads(void) {
     return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------------------------------
+ * torchaudio.transforms.Resample(orig_freq, new_freq)(wave) -- the call at
+ * processors/spectrogram_generator.py:117-121.  torchaudio 2.4.1 (requirements.txt pin, absent
+ * from /root/reference): functional._get_sinc_resample_kernel + _apply_sinc_resample_kernel with
+ * the defaults sinc_interp_hann, lowpass_filter_width = 6, rolloff = 0.99:
+ *   orig, new    = freqs / gcd;  base = min(orig, new) * rolloff;  width = ceil(6 * orig / base)
+ *   t[j][k]      = clamp((-j/new + (k - width)/orig) * base, -6, 6)          (float64)
+ *   kernel[j][k] = (t == 0 ? 1 : sin(pi t)/(pi t)) * cos(pi t / 12)^2 * base/orig -> float32
+ *   y[i*new + j] = sum_k kernel[j][k] * xpad[i*orig + k],  xpad = x with `width` zeros in front
+ *   output length ceil(new * L / orig)
+ * The dot product is accumulated in double here (the order of torch's fp32 conv1d is not
+ * specified); the device kernel is compared within a stated tolerance.  out_taps may be NULL. */
+static int gcd_int(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
+int64_t orc_resample_length(int64_t L, int orig_freq, int new_freq) {
+    int g = gcd_int(orig_freq, new_freq);
+    int64_t orig = orig_freq / g, nw = new_freq / g;
+    return (nw * L + orig - 1) / orig;
+}
+
+int orc_resample(const float* wave, int64_t L, int orig_freq, int new_freq, float* out) {
+    if (!wave || !out || L <= 0 || orig_freq <= 0 || new_freq <= 0) return -1;
+    const int g = gcd_int(orig_freq, new_freq);
+    const int orig = orig_freq / g, nw = new_freq / g;
+    const double lpw = 6.0, rolloff = 0.99;
+    const double base = (orig < nw ? orig : nw) * rolloff;
+    const int width = (int)ceil(lpw * orig / base);
+    const int K = 2 * width + orig;
+    float* taps = (float*)malloc(sizeof(float) * (size_t)nw * K);
+    if (!taps) return -2;
+    for (int j = 0; j < nw; j++)
+        for (int k = 0; k < K; k++) {
+            double t = ((double)(-j) / nw + (double)(k - width) / orig) * base;
+            if (t < -lpw) t = -lpw;
+            if (t > lpw) t = lpw;
+            double w = cos(t * M_PI / lpw / 2);
+            w *= w;
+            t *= M_PI;
+            double sinc = t == 0.0 ? 1.0 : sin(t) / t;
+            taps[(size_t)j * K + k] = (float)(sinc * w * (base / orig));
+        }
+    const int64_t out_len = orc_resample_length(L, orig_freq, new_freq);
+#pragma omp parallel for schedule(static)
+    for (int64_t o = 0; o < out_len; o++) {
+        const int64_t i = o / nw;
+        const int j = (int)(o - i * nw);
+        const float* t = taps + (size_t)j * K;
+        double acc = 0.0;
+        for (int k = 0; k < K; k++) {
+            const int64_t s = i * orig - width + k;
+            if (s >= 0 && s < L) acc += (double)t[k] * (double)wave[s];
+        }
+        out[o] = (float)acc;
+    }
+    free(taps);
+    return 0;
+}

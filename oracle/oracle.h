@@ -16,6 +16,9 @@ int64_t orc_num_frames(int64_t L, int hop);
 int orc_logmel(const float* wave, int64_t L, int sample_rate, int n_fft, int hop, int n_mels,
                const float* fb_or_null, float* out);
 
+int64_t orc_resample_length(int64_t L, int orig_freq, int new_freq);
+int orc_resample(const float* wave, int64_t L, int orig_freq, int new_freq, float* out);
+
 void orc_assign_ref(const float* x, int64_t n, int d, const float* c, int k, int64_t* ids,
                     float* dis);
 void orc_assign(const float* x, int64_t n, int d, const float* c, int k, int64_t* ids,

@@ -41,6 +41,12 @@ class OracleBackend(HostHelpers):
     def synchronize(self):
         pass
 
+    def resample(self, wave, orig_freq, new_freq):
+        w = self._f32(wave)
+        if w.dim() == 1:
+            return torch.from_numpy(oracle.resample(w.numpy(), orig_freq, new_freq))
+        return torch.from_numpy(np.stack([oracle.resample(r.numpy(), orig_freq, new_freq) for r in w]))
+
     def l2norm_rows(self, x, out=None):
         return torch.from_numpy(oracle.l2norm_rows(self._f32(x).numpy()))
 

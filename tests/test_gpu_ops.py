@@ -247,3 +247,49 @@ def test_logmel_full_length_clip_shapes(be, oracle):
     assert got.shape == (3, 64, 1723)
     ref = oracle.logmel(w[1])
     assert _logmel_tolerance(got[1], ref).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# resampler
+@pytest.mark.parametrize("orig_freq,new_freq", [(44100, 22050), (48000, 22050), (16000, 22050), (22050, 16000)])
+def test_resample_matches_oracle(be, oracle, orig_freq, new_freq):
+    rng = np.random.default_rng(orig_freq)
+    for L, B in ((1, 1), (37, 3), (20001, 2), (orig_freq, 4)):
+        w = rng.standard_normal((B, L)).astype(np.float32)
+        got = be.to_host(be.resample(w, orig_freq, new_freq))
+        assert got.shape == (B, be.resample_length(L, orig_freq, new_freq))
+        taps = be.resample_taps(orig_freq, new_freq)[0]
+        # fp32 fma chain of K taps against the oracle's double dot: |err| <= K * 2^-24 * sum|t||x|
+        tol = taps.shape[1] * 2.0 ** -24 * np.abs(taps).sum(1).max() * np.abs(w).max()
+        for b in range(B):
+            want = oracle.resample(w[b], orig_freq, new_freq)
+            assert np.abs(got[b] - want).max() <= tol
+
+
+def test_resample_kernels_agree_bitwise(be, monkeypatch):
+    """The LDS-tiled kernel and the plain one run the same ascending-k fma chain."""
+    for orig_freq, new_freq, L in ((44100, 22050, 50001), (48000, 22050, 30011), (11025, 22050, 999),
+                                   (96000, 22050, 40000), (16000, 22050, 16000)):
+        w = torch.randn(3, L, device=be.device)
+        monkeypatch.delenv("AT_RESAMPLE_SIMPLE", raising=False)
+        tiled = be.resample(w, orig_freq, new_freq)
+        monkeypatch.setenv("AT_RESAMPLE_SIMPLE", "1")
+        plain = be.resample(w, orig_freq, new_freq)
+        assert torch.equal(tiled, plain), (orig_freq, new_freq)
+    monkeypatch.delenv("AT_RESAMPLE_SIMPLE", raising=False)
+
+
+def test_resample_strided_rows_and_class(be, oracle):
+    from audio_tokens_amd.ops import Resample
+    w = torch.randn(3, 5000, device=be.device)
+    view = w[:, :4096]                                   # row stride 5000, length 4096
+    got = be.to_host(Resample(48000, 22050, backend=be)(view))
+    for b in range(3):
+        want = oracle.resample(view[b].cpu().numpy(), 48000, 22050)
+        np.testing.assert_allclose(got[b], want, rtol=0, atol=1e-5)
+    same = Resample(22050, 22050, backend=be)(view)
+    assert same is view
+    one = Resample(44100, 22050, backend=be)(view[0])
+    assert tuple(one.shape) == (2048,)
+    with pytest.raises(ValueError):
+        Resample(44100.5, 22050, backend=be)

@@ -101,6 +101,32 @@ def test_stage_class_surface(workdir):
     assert [s["filename"] for s in specs] == [f"{y}.npy" for y in split["train"] if y in waves]
 
 
+def test_generator_resamples_foreign_rates(workdir, oracle):
+    """A 16-bit stereo 44.1 kHz .wav: decode -> mono -> device resampler -> log-mel, as the reference's
+    preprocess_waveform + generate_mel_spectrogram (spectrogram_generator.py:105-126)."""
+    import wave as wavmod
+    from audio_tokens_amd.processors import SpectrogramGenerator
+    cfg, split, waves = workdir
+    rng = np.random.default_rng(5)
+    pcm = (rng.standard_normal((44100, 2)) * 3000).astype("<i2")
+    y = "zzwavclip01"
+    p = Path(cfg.audio_source_path) / "bal_train" / y[:2]
+    p.mkdir(parents=True, exist_ok=True)
+    with wavmod.open(str(p / f"{y}.wav"), "wb") as f:
+        f.setnchannels(2); f.setsampwidth(2); f.setframerate(44100); f.writeframes(pcm.tobytes())
+    sg = SpectrogramGenerator(cfg)
+    w = sg.preprocess_waveform(sg.find_audio_file(y))
+    assert tuple(w.shape) == (1, 22050) and w.device.type == "cuda"
+    mono = (pcm.astype(np.float32) / 32768.0).mean(1, dtype=np.float32)
+    want = oracle.resample(mono, 44100, 22050)
+    np.testing.assert_allclose(w[0].cpu().numpy(), want, rtol=0, atol=2e-6)
+    specs = sg.populate_specs([y, split["train"][0]])          # mixed host / device clips, two lengths
+    assert [s["filename"] for s in specs] == [f"{y}.wav", f"{split['train'][0]}.npy"]
+    ref = oracle.logmel(w[0].cpu().numpy())
+    P, Pr = 10.0 ** (specs[0]["spec"].double().numpy() / 10), 10.0 ** (ref.astype(np.float64) / 10)
+    assert (np.abs(P - Pr) <= 2e-5 * Pr + 1e-9 * Pr.max(0, keepdims=True) + 1e-14).all()
+
+
 def test_device_pipeline_matches_oracle(be, oracle):
     from audio_tokens_amd.pipeline import DevicePipeline
     from audio_tokens_amd.synth import synth_clips
