@@ -9,6 +9,7 @@ not here.)
 from __future__ import annotations
 
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -303,12 +304,16 @@ class HipBackend(HostHelpers):
         guess, gdis = self.assign_pruned(x, c, self.visit_order(gx, None, ng), cperm, gnbr, mode=1)
         return self.assign_pruned(x, c, self.visit_order(guess, gdis, c.shape[0]), cperm, dmin, want_dist=want_dist)
 
-    def assign_pruned(self, x, c, order, cperm, dmin, want_dist=True, mode=0):
+    def assign_pruned(self, x, c, order, cperm, dmin, want_dist=True, mode=0, filter=None):
         """mode 0: same result as assign(); `order` = visit_order(...) of the guesses.
         mode 1: best centroid among the groups named by each 32-row tile (order = visit_order of
-        group ids) -- a guess generator."""
+        group ids) -- a guess generator.
+        filter (default: on at d = 64 unless AT_FILTER=0): fp16-split first stage, same bits out."""
         x, c = self._f32(x), self._f32(c)
         n, d = x.shape
+        if filter is None:
+            filter = os.environ.get("AT_FILTER", "1") != "0"
+        use_filter = bool(filter) and d == 64
         k = c.shape[0]
         order, hint_sorted = order
         ng = cperm.numel() // 32
@@ -323,12 +328,35 @@ class HipBackend(HostHelpers):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(torch.cuda.current_stream(self.device))
             _lib.check(self.lib.at_assign_pruned_f32(self.ctx.handle, _ptr(x), n, d, _ptr(c), k, _ptr(order),
-                                                     _ptr(hint_sorted), _ptr(cperm), ng, _ptr(dmin), mode, 1, _ptr(ids),
+                                                     _ptr(hint_sorted), _ptr(cperm), ng, _ptr(dmin),
+                                                     mode | (2 if use_filter else 0), 1, _ptr(ids),
                                                      _ptr(dist), self._stream()))
         if rec is not None:
             e1.record(torch.cuda.current_stream(self.device))
             rec.append(("pruned" if mode == 0 else "coarse", n, d, k, e0, e1))
         return ids, dist
+
+    def filter_stats(self, reset=True):
+        """(rows swept by the fp16-split filter, rows it handed to the fp32 sweep) since the last reset."""
+        a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+        _lib.check(self.lib.at_filter_stats(self.ctx.handle, ctypes.byref(a), ctypes.byref(b), 1 if reset else 0))
+        return a.value, b.value
+
+    def filter_probe(self, x, c, order, cperm, dmin):
+        """Test hook: stage 1 only -> (winner ids, approx [n, 2] = (P of the winner, gap to runner-up), listed)."""
+        x, c = self._f32(x), self._f32(c)
+        n, d = x.shape
+        k = c.shape[0]
+        order, hint_sorted = order
+        ng = cperm.numel() // 32
+        ids = self.empty((n,), torch.int64)
+        approx = self.empty((n, 2), torch.float32)
+        listed = ctypes.c_int64(0)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_filter_probe_f32(self.ctx.handle, _ptr(x), n, d, _ptr(c), k, _ptr(order),
+                                                    _ptr(hint_sorted), _ptr(cperm), ng, _ptr(dmin), _ptr(ids),
+                                                    _ptr(approx), ctypes.byref(listed), self._stream()))
+        return ids, approx, listed.value
 
     def gather_rows(self, x, idx) -> torch.Tensor:
         x = self._f32(x)

@@ -1246,7 +1246,7 @@ int at_prune_prepass(at_ctx* ctx, const float* x, int64_t n, int d, const float*
 template <int D, int NB>
 static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c, int k, const uint32_t* order,
                          const uint32_t* hint_sorted, const int32_t* cperm, int ng, const float* dmin, int mode,
-                         bool prepass_done, int64_t* ids, float* dist, hipStream_t stream) {
+                         bool prepass_done, bool filter, int64_t* ids, float* dist, hipStream_t stream) {
     const int kp = ng * 32;
     const int ngw = (ng + 31) / 32;
     const size_t img_bytes = sizeof(float) * (size_t)ng * tile_floats(D, 1);
@@ -1264,15 +1264,51 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
     }
     const size_t lds = 2 * sizeof(float) * tile_floats(D, 1);
     const int64_t rows_per_wg = 32 * NB;
+    const uint32_t* order2 = order;
+    const uint32_t* hint2 = hint_sorted;
+    int64_t n2 = n;
+    if (filter && D == 64) {
+        // Stage 1: fp16-split filter (filter.hip) names the winner of every row whose runner-up is
+        // provably out of reach and lists the others; stage 2 below redoes the listed rows with the
+        // fp32 sweep.  Coarse mode (guesses only) needs neither the list nor stage 2.
+        unsigned* misc = static_cast<unsigned*>(at_ws(ctx, WS_FILTER_MISC, 256, stream));
+        uint32_t* list = static_cast<uint32_t*>(at_ws(ctx, WS_FILTER_LIST, sizeof(uint32_t) * 4 * ((size_t)n + 64), stream));
+        if (!misc || !list) return AT_E_NOMEM;
+        int rc = at_filter_sweep(ctx, x, n, D, c, k, order, cperm, ng, bd, mask, ngw, mode == 0 ? 1 : 0, ids, misc, list,
+                                 nullptr, stream);
+        if (rc) return rc;
+        if (dist) {
+            rc = mode == 0 ? at_exact_dist_rows(ctx, x, n, D, c, k, ids, dist, order, hint_sorted, bd, stream)
+                           : at_exact_dist_rows(ctx, x, n, D, c, k, ids, dist, nullptr, nullptr, nullptr, stream);
+            if (rc) return rc;
+        }
+        if (mode != 0) return AT_OK;
+        unsigned listed = 0;
+        AT_HIP(hipMemcpyAsync(&listed, misc + 1, sizeof listed, hipMemcpyDeviceToHost, stream));
+        AT_HIP(hipStreamSynchronize(stream));
+        ctx->filter_rows += n;
+        ctx->filter_listed += listed;
+        if (listed == 0) return AT_OK;
+        n2 = listed < 64 ? 64 : (int64_t)listed;
+        uint32_t* sorted = list + ((size_t)n + 64);
+        uint32_t* order_amb = sorted + ((size_t)n + 64);
+        uint32_t* hint_amb = order_amb + ((size_t)n + 64);
+        rc = at_filter_gather_ambiguous(ctx, list, sorted, listed, n2, order, ids, order_amb, hint_amb, stream);
+        if (rc) return rc;
+        order2 = order_amb;
+        hint2 = hint_amb;
+        rc = at_prune_prepass(ctx, x, n2, D, c, k, order2, hint2, dmin, ng, bd, mask, ngw, 0, stream);
+        if (rc) return rc;
+    }
     // d = 64: register-staged A operand (no LDS); AT_PRUNE_KERNEL=0 selects the LDS-DMA form (A/B aid)
     const char* ev = std::getenv("AT_PRUNE_KERNEL");
     if (!(ev && std::atoi(ev) == 0) && D == 64 && NB <= 2)
-        hipLaunchKernelGGL((assign_mfma_pruned_reg_kernel<D, NB>), dim3((unsigned)((n + rows_per_wg - 1) / rows_per_wg)),
-                           dim3(64), 0, stream, x, (long)n, img, ng, order, hint_sorted, bd, mask, ngw,
+        hipLaunchKernelGGL((assign_mfma_pruned_reg_kernel<D, NB>), dim3((unsigned)((n2 + rows_per_wg - 1) / rows_per_wg)),
+                           dim3(64), 0, stream, x, (long)n2, img, ng, order2, hint2, bd, mask, ngw,
                            reinterpret_cast<long*>(ids), dist);
     else
-        hipLaunchKernelGGL((assign_mfma_pruned_kernel<D, NB>), dim3((unsigned)((n + rows_per_wg - 1) / rows_per_wg)),
-                           dim3(64), lds, stream, x, (long)n, img, ng, order, hint_sorted, bd, mask, ngw,
+        hipLaunchKernelGGL((assign_mfma_pruned_kernel<D, NB>), dim3((unsigned)((n2 + rows_per_wg - 1) / rows_per_wg)),
+                           dim3(64), lds, stream, x, (long)n2, img, ng, order2, hint2, bd, mask, ngw,
                            reinterpret_cast<long*>(ids), dist);
     AT_LAUNCH_CHECK();
     return AT_OK;
@@ -1284,8 +1320,10 @@ extern "C" int at_assign_pruned_f32(at_ctx* ctx, const float* x, int64_t n, int 
                                     float* dist, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     AT_REQUIRE(ctx, "at_assign_pruned_f32: ctx is null");
-    AT_REQUIRE(x && c && order && hint_sorted && cperm && (dmin || mode == 1) && ids, "at_assign_pruned_f32: null pointer");
-    AT_REQUIRE(mode == 0 || mode == 1, "at_assign_pruned_f32: mode must be 0 or 1");
+    AT_REQUIRE(x && c && order && hint_sorted && cperm && (dmin || (mode & 1)) && ids, "at_assign_pruned_f32: null pointer");
+    AT_REQUIRE(mode >= 0 && mode <= 3, "at_assign_pruned_f32: mode must be 0..3");
+    const bool filter = (mode & 2) != 0 && d == 64;
+    mode &= 1;
     AT_REQUIRE(d == 64 || d == 128, "at_assign_pruned_f32: d must be 64 or 128");
     AT_REQUIRE(n >= 20 && n < (int64_t)UINT32_MAX && k > 0 && ng > 0 && ng <= 512 && ng * 32 >= k,
                "at_assign_pruned_f32: bad sizes n=%lld k=%d ng=%d", (long long)n, k, ng);
@@ -1293,11 +1331,11 @@ extern "C" int at_assign_pruned_f32(at_ctx* ctx, const float* x, int64_t n, int 
     AT_HIP(hipSetDevice(ctx->device));
     if (d == 64) {
         const char* e = std::getenv("AT_PRUNE_NB");
-        if (e && std::atoi(e) == 4) return launch_pruned<64, 4>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, prepass_done != 0, ids, dist, stream);
-        if (e && std::atoi(e) == 1) return launch_pruned<64, 1>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, prepass_done != 0, ids, dist, stream);
-        return launch_pruned<64, 2>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, prepass_done != 0, ids, dist, stream);
+        if (e && std::atoi(e) == 4) return launch_pruned<64, 4>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, prepass_done != 0, filter, ids, dist, stream);
+        if (e && std::atoi(e) == 1) return launch_pruned<64, 1>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, prepass_done != 0, filter, ids, dist, stream);
+        return launch_pruned<64, 2>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, prepass_done != 0, filter, ids, dist, stream);
     }
-    return launch_pruned<128, 2>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, prepass_done != 0, ids, dist, stream);
+    return launch_pruned<128, 2>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, prepass_done != 0, filter, ids, dist, stream);
 }
 
 // The pre-pass of at_assign_pruned_f32 on its own (per-row bound + per-tile group masks, kept in the
@@ -1317,4 +1355,43 @@ extern "C" int at_prune_mask_f32(at_ctx* ctx, const float* x, int64_t n, int d, 
     uint32_t* mask = static_cast<uint32_t*>(at_ws(ctx, WS_PRUNE_MASK, sizeof(uint32_t) * (size_t)ntile32 * ngw, stream));
     if (!bd || !mask) return AT_E_NOMEM;
     return at_prune_prepass(ctx, x, n, d, c, k, order, hint_sorted, dmin, ng, bd, mask, ngw, mode, stream);
+}
+
+// fp16-split filter: rows swept / rows handed to the fp32 redo since the last reset.
+extern "C" int at_filter_stats(at_ctx* ctx, int64_t* rows, int64_t* listed, int reset) {
+    AT_REQUIRE(ctx && rows && listed, "at_filter_stats: bad arguments");
+    *rows = ctx->filter_rows;
+    *listed = ctx->filter_listed;
+    if (reset) ctx->filter_rows = ctx->filter_listed = 0;
+    return AT_OK;
+}
+
+// Test hook: pre-pass + stage 1 only.  approx[2i] = approximate |c|^2 - 2 x.c of row i's winner,
+// approx[2i+1] = gap to the runner-up; ids = the winners; *listed = rows the filter would hand to the
+// fp32 sweep; tau_ab[0..1] = the coefficients of the acceptance threshold tau = a (|x|^2 + max|c|^2) + b.
+extern "C" int at_filter_probe_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
+                                   const uint32_t* order, const uint32_t* hint_sorted, const int32_t* cperm, int ng,
+                                   const float* dmin, int64_t* ids, float* approx, int64_t* listed, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AT_REQUIRE(ctx && x && c && order && hint_sorted && cperm && dmin && ids && approx && listed,
+               "at_filter_probe_f32: null pointer");
+    AT_REQUIRE(d == 64 && n >= 20 && n < (int64_t)UINT32_MAX && k > 0 && ng > 0 && ng <= 512 && ng * 32 >= k,
+               "at_filter_probe_f32: bad sizes");
+    AT_HIP(hipSetDevice(ctx->device));
+    const int ngw = (ng + 31) / 32;
+    const int64_t ntile32 = (n + 31) / 32;
+    float* bd = static_cast<float*>(at_ws(ctx, WS_PRUNE_BD, sizeof(float) * (size_t)n, stream));
+    uint32_t* mask = static_cast<uint32_t*>(at_ws(ctx, WS_PRUNE_MASK, sizeof(uint32_t) * (size_t)ntile32 * ngw, stream));
+    unsigned* misc = static_cast<unsigned*>(at_ws(ctx, WS_FILTER_MISC, 256, stream));
+    uint32_t* list = static_cast<uint32_t*>(at_ws(ctx, WS_FILTER_LIST, sizeof(uint32_t) * 4 * ((size_t)n + 64), stream));
+    if (!bd || !mask || !misc || !list) return AT_E_NOMEM;
+    int rc = at_prune_prepass(ctx, x, n, d, c, k, order, hint_sorted, dmin, ng, bd, mask, ngw, 0, stream);
+    if (rc) return rc;
+    rc = at_filter_sweep(ctx, x, n, d, c, k, order, cperm, ng, bd, mask, ngw, 1, ids, misc, list, approx, stream);
+    if (rc) return rc;
+    unsigned cnt = 0;
+    AT_HIP(hipMemcpyAsync(&cnt, misc + 1, sizeof cnt, hipMemcpyDeviceToHost, stream));
+    AT_HIP(hipStreamSynchronize(stream));
+    *listed = cnt;
+    return AT_OK;
 }

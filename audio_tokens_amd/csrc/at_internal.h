@@ -23,6 +23,9 @@ enum at_ws_slot {
     WS_PRUNE_MASK,     // pruned sweep: per 32-row tile, one bit per 32-centroid group
     WS_PRUNE_STATS,    // pruned sweep: {accumulators computed, accumulators of the dense sweep}
     WS_RESAMPLE_TAPS,  // resampler: polyphase filter taps [new][2*width + orig]
+    WS_CENT_IMG16,     // fp16-split filter: centroid fragments (hi, lo) per group + |c|^2 + indices
+    WS_FILTER_LIST,    // fp16-split filter: listed positions, sorted copy, order/hint of the redo pass
+    WS_FILTER_MISC,    // fp16-split filter: max|c|^2 bits, list length; running totals for at_filter_stats
     WS_NSLOTS
 };
 
@@ -34,6 +37,7 @@ struct at_ctx {
     int fb_sr, fb_nfft, fb_nmels, fb_nw;
     const float* fb_user;
     int rs_orig, rs_new;  // what WS_RESAMPLE_TAPS currently holds
+    int64_t filter_rows, filter_listed;  // fp16-split filter: rows swept / rows handed to the fp32 redo
 };
 
 int at_fail(int code, const char* fmt, ...);
@@ -60,5 +64,16 @@ void* at_ws(at_ctx* ctx, int slot, size_t bytes, hipStream_t stream);
     do {                                                       \
         if (!(cond)) return at_fail(AT_E_INVALID, __VA_ARGS__); \
     } while (0)
+
+// filter.hip (fp16-split filter of the pruned sweep)
+int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k, const uint32_t* order,
+                    const int32_t* cperm, int ng, const float* bd, const uint32_t* mask, int ngw, int collect,
+                    int64_t* ids, unsigned* misc, uint32_t* amb_list, float* approx_out, hipStream_t stream);
+int at_exact_dist_rows(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k, const int64_t* ids,
+                       float* dist, const uint32_t* order, const uint32_t* hint_sorted, const float* bd,
+                       hipStream_t stream);
+int at_filter_gather_ambiguous(at_ctx* ctx, uint32_t* amb_list, uint32_t* amb_sorted, int64_t m_valid, int64_t m,
+                               const uint32_t* order, const int64_t* ids, uint32_t* order_amb, uint32_t* hint_amb,
+                               hipStream_t stream);
 
 static inline bool at_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

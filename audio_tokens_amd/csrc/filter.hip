@@ -1,0 +1,453 @@
+// filter.hip -- fp16-split filter for the exact pruned sweep (used by at_assign_pruned_f32).
+//
+// Accelerates faiss.IndexFlatL2.search(x, 1) at processors/spec_tokenizer.py:77 and inside
+// faiss.Kmeans.train (processors/cluster_creator.py:54-56 of danavery/audio-tokens) without
+// changing an output bit.
+//
+// The fp32 MFMA runs at 1/16 of the fp16 MFMA rate on gfx950.  Every fp32 value v is split as
+// v = hi + lo + r with hi = fp16(v), lo = fp16(v - hi); then
+//     x.c  ~=  hi_x.hi_c + hi_x.lo_c + lo_x.hi_c          (three v_mfma_f32_32x32x16_f16, fp32 accumulate)
+// with an error that is bounded a priori (below).  The sweep keeps, per row, the smallest and the
+// second smallest approximate distance P(j) = |c_j|^2 - 2 ip16(x, c_j) over the candidates the group
+// masks admit.  With eps bounding |P(j) + |x|^2 - T(j)| (T = true squared distance) and delta bounding
+// |D(j) - T(j)| for the distance D the fp32 contract computes (prune.hip), the contract's arg-min
+// j* satisfies D(j*) <= D(j) for all j, hence P(j*) <= P(j) + 2 delta + 2 eps =: P(j) + tau.
+// So when the runner-up is more than tau above the best, the best IS j* -- whatever the tie rule --
+// and only its distance remains to be evaluated with the contract's fmaf chain (at_exact_dist_rows).
+// Rows that fail the test (about 2-3 % on log-mel frames), rows or centroids outside the fp16 range
+// and rows with non-finite values are listed and redone by the fp32 sweep.
+//
+// Error budget (s = |x|, t = max |c|, H = s^2 + t^2 >= 2 s t, u = 2^-24, m = 3 d / 16 MFMAs):
+//   representation   |x.c - (three kept terms)| <= 3*2^-22 * s t + 2 q (s + t),  q = sqrt(d) 2^-25
+//                    (fp16 rounding 2^-11 relative, 2^-25 absolute below the normal range)
+//   accumulation     each MFMA adds 16 exact products to an fp32 accumulator; charged 17 roundings
+//                    of one ulp (2u) of the running magnitude <= 1.01 s t each:  34 m u * 1.01 s t
+//   |c|^2, |x|^2     fmaf chains: d u each, relative
+//   forming P        one fma: u (t^2 + 2 s t)
+//   eps <= H (17 m u 1.01 + 3*2^-23 + d u 1.01 + 2 u + 2 q) + 4 q          (doubled ip terms folded in)
+//   tau  = 2 (2d + 8) u 1.01 H + 2 eps
+// tests/test_gpu_ops.py::test_filter_error_bound measures the actual error against float64.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "at_internal.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int WG = 256;
+constexpr unsigned NONE = 0xffffffffu;
+constexpr float RANGE_SQ = 1073741824.0f;  // 2^30: |v| < 2^15 for every component
+
+__host__ __device__ constexpr size_t group_bytes(int d) { return (size_t)32 * d * 4 + 1024; }
+
+// Image of group g: fragments [s = feature/16][hi, lo][lane][8 halves] (lane = 32 * ((f % 16) / 8) +
+// slot, exactly the A operand of v_mfma_f32_32x32x16_f16, one coalesced 1 KiB load per fragment),
+// then |c|^2 of the 32 slots (+inf for padding) and, 512 bytes further, their centroid indices.
+__global__ void __launch_bounds__(WG) prep_centroids_f16_kernel(const float* __restrict__ c, int k, int d,
+                                                                const int32_t* __restrict__ cperm,
+                                                                unsigned char* __restrict__ img) {
+    const int g = blockIdx.x;
+    unsigned char* out = img + (size_t)g * group_bytes(d);
+    _Float16* frag = reinterpret_cast<_Float16*>(out);
+    for (int e = threadIdx.x; e < 32 * d; e += WG) {
+        const int i = e / d, f = e - i * d;
+        const int row = cperm[g * 32 + i];
+        const float v = (row >= 0 && row < k) ? c[(size_t)row * d + f] : 0.0f;
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        const int s = f >> 4, lane = 32 * ((f & 15) >> 3) + i, el = f & 7;
+        frag[((size_t)(2 * s + 0) * 64 + lane) * 8 + el] = hi;
+        frag[((size_t)(2 * s + 1) * 64 + lane) * 8 + el] = lo;
+    }
+    float* cn = reinterpret_cast<float*>(out + (size_t)32 * d * 4);
+    unsigned* idx = reinterpret_cast<unsigned*>(out + (size_t)32 * d * 4 + 512);
+    for (int i = threadIdx.x; i < 32; i += WG) {
+        const int row = cperm[g * 32 + i];
+        float nrm = __builtin_inff();
+        if (row >= 0 && row < k) {
+            nrm = 0.0f;
+            for (int f = 0; f < d; f++) {
+                const float v = c[(size_t)row * d + f];
+                nrm = __builtin_fmaf(v, v, nrm);
+            }
+        }
+        cn[i] = nrm;
+        idx[i] = (row >= 0 && row < k) ? (unsigned)row : NONE;
+    }
+}
+
+__global__ void __launch_bounds__(WG) max_sqnorm_bits_kernel(const float* __restrict__ C, int k, int d,
+                                                             unsigned* __restrict__ out_bits) {
+    const int c = blockIdx.x * WG + threadIdx.x;
+    float s = 0.0f;
+    if (c < k)
+        for (int f = 0; f < d; f++) s = __builtin_fmaf(C[(size_t)c * d + f], C[(size_t)c * d + f], s);
+    // non-negative floats (and +inf, NaN above them) order like their bit patterns
+    atomicMax(out_bits, __float_as_uint(s) & 0x7fffffffu);
+}
+
+// One wavefront per workgroup, structure of assign_mfma_pruned_reg_kernel (assign.hip): the wave
+// walks the groups its 32*NB rows need, the fragments of the next group are fetched into registers
+// while the current one multiplies.  misc[0] = max |c|^2 bits, misc[1] = ambiguous-row counter.
+template <int D, int NB>
+__global__ void __launch_bounds__(64, 2)
+assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char* __restrict__ img, int ng,
+                        const uint32_t* __restrict__ order, const float* __restrict__ bd_in,
+                        const uint32_t* __restrict__ mask, int ngw, unsigned* __restrict__ misc, float tau_a,
+                        float tau_b, int collect, long* __restrict__ ids, uint32_t* __restrict__ amb_list,
+                        float* __restrict__ approx_out) {
+    constexpr int NS = D / 16;
+    constexpr int MAXW = 16;
+    constexpr size_t GB = group_bytes(D);
+
+    const int lane = threadIdx.x;
+    const int j = lane & 31;
+    const int h = lane >> 5;
+    const long pos0 = (long)blockIdx.x * (32 * NB);
+    const long ntile32 = (n + 31) / 32;
+    const float cnmax = __uint_as_float(misc[0]);
+    const bool c_bad = !(cnmax < RANGE_SQ);
+
+    half8 xh[NB][NS], xl[NB][NS];
+    float b1[NB], b2[NB], tau[NB];
+    unsigned i1[NB];
+    bool bad[NB];
+    long rowid[NB];
+    uint32_t mw[NB][MAXW];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        long pos = pos0 + 32 * b + j;
+        if (pos >= n) pos = n - 1;
+        const long r = (long)order[pos];
+        rowid[b] = r;
+        const f32x4* p = reinterpret_cast<const f32x4*>(X + r * D);
+        float part = 0.0f;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const f32x4 u = p[4 * s + 2 * h], v = p[4 * s + 2 * h + 1];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                part = __builtin_fmaf(u[e], u[e], part);
+                const _Float16 hu = (_Float16)u[e];
+                xh[b][s][e] = hu;
+                xl[b][s][e] = (_Float16)(u[e] - (float)hu);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                part = __builtin_fmaf(v[e], v[e], part);
+                const _Float16 hv = (_Float16)v[e];
+                xh[b][s][4 + e] = hv;
+                xl[b][s][4 + e] = (_Float16)(v[e] - (float)hv);
+            }
+        }
+        const float nrm = part + __shfl_xor(part, 32);
+        tau[b] = __builtin_fmaf(tau_a, nrm * 1.001f + cnmax, tau_b);
+        bad[b] = c_bad || !(nrm < RANGE_SQ);
+        const float bd = bd_in[pos];
+        // candidates above the cap can neither be the arg-min nor within tau of it: the guess itself
+        // (always admitted by the masks) has P <= bd - |x|^2 + eps
+        const float cap = bd < __builtin_inff() ? (bd - nrm) + 3.0f * tau[b] : __builtin_inff();
+        b1[b] = cap;
+        b2[b] = cap;
+        i1[b] = NONE;
+        const long tile = pos0 / 32 + b;
+#pragma unroll
+        for (int w = 0; w < MAXW; w++) {
+            uint32_t m = 0;
+            if (w < ngw && tile < ntile32) m = mask[(size_t)tile * ngw + w];
+            mw[b][w] = __builtin_amdgcn_readfirstlane(m);
+        }
+    }
+    uint32_t any[MAXW];
+#pragma unroll
+    for (int w = 0; w < MAXW; w++) {
+        any[w] = 0;
+#pragma unroll
+        for (int b = 0; b < NB; b++) any[w] |= mw[b][w];
+    }
+    auto word_of = [&](const uint32_t (&m)[MAXW], int w) -> uint32_t {
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < MAXW; i++)
+            if (i == w) v = m[i];
+        return v;
+    };
+    auto next_group = [&](int from) {
+        int w = from >> 5;
+        if (w >= ngw) return ng;
+        uint32_t bits = word_of(any, w) & (0xffffffffu << (from & 31));
+        while (bits == 0) {
+            if (++w >= ngw) return ng;
+            bits = word_of(any, w);
+        }
+        const int g = (w << 5) + __builtin_ctz(bits);
+        return g < ng ? g : ng;
+    };
+
+    auto load_group = [&](int g, half8 (&ah)[NS], half8 (&al)[NS], f32x4 (&cn)[4]) {
+        const unsigned char* base = img + (size_t)g * GB;
+        const half8* fr = reinterpret_cast<const half8*>(base);
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            ah[s] = fr[(2 * s + 0) * 64 + lane];
+            al[s] = fr[(2 * s + 1) * 64 + lane];
+        }
+        const float* cnp = reinterpret_cast<const float*>(base + (size_t)32 * D * 4);
+#pragma unroll
+        for (int q = 0; q < 4; q++) cn[q] = *reinterpret_cast<const f32x4*>(cnp + 8 * q + 4 * h);
+    };
+    auto compute_group = [&](int g, const half8 (&ah)[NS], const half8 (&al)[NS], const f32x4 (&cnv)[4]) {
+        const uint32_t gbit = 1u << (g & 31);
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            if ((word_of(mw[b], g >> 5) & gbit) == 0u) continue;  // wave-uniform
+            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], xh[b][s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xl[b][s], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < NS; s++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[b][s], acc, 0, 0, 0);
+            float P[16];
+            float m = __builtin_inff();
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                P[r] = __builtin_fmaf(-2.0f, acc[r], cnv[r >> 2][r & 3]);
+                m = __builtin_fminf(m, P[r]);
+            }
+            if (__builtin_amdgcn_ballot_w64(m < b2[b]) != 0) {
+                const float old = b1[b];
+                float v1 = b1[b], v2 = b2[b];
+                unsigned lr = 0;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    v2 = __builtin_amdgcn_fmed3f(v1, v2, P[r]);
+                    lr = P[r] < v1 ? (unsigned)r : lr;
+                    v1 = __builtin_fminf(v1, P[r]);
+                }
+                b1[b] = v1;
+                b2[b] = v2;
+                if (v1 < old) i1[b] = (unsigned)g * 32u + 4u * h + (lr & 3u) + 8u * (lr >> 2);
+            }
+        }
+    };
+
+    half8 ahA[NS], alA[NS], ahB[NS], alB[NS];
+    f32x4 cnA[4], cnB[4];
+    int g = next_group(0);
+    if (g < ng) load_group(g, ahA, alA, cnA);
+    while (g < ng) {
+        const int g1 = next_group(g + 1);
+        if (g1 < ng) load_group(g1, ahB, alB, cnB);
+        compute_group(g, ahA, alA, cnA);
+        if (g1 >= ng) break;
+        const int g2 = next_group(g1 + 1);
+        if (g2 < ng) load_group(g2, ahA, alA, cnA);
+        compute_group(g1, ahB, alB, cnB);
+        g = g2;
+    }
+
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const float o1 = __shfl_xor(b1[b], 32), o2 = __shfl_xor(b2[b], 32);
+        const unsigned oi = (unsigned)__shfl_xor((int)i1[b], 32);
+        const float n1 = __builtin_fminf(b1[b], o1);
+        const float n2 = __builtin_fminf(__builtin_fmaxf(b1[b], o1), __builtin_fminf(b2[b], o2));
+        const unsigned ni = o1 < b1[b] ? oi : i1[b];
+        const long pos = pos0 + 32 * b + j;
+        const bool mine = h == 0 && pos < n;
+        const bool unique = ni != NONE && !bad[b] && n1 > -__builtin_inff() && (n2 - n1) > tau[b];
+        if (mine) {
+            unsigned id = NONE;
+            if (ni != NONE) id = reinterpret_cast<const unsigned*>(img + (size_t)(ni >> 5) * GB + (size_t)32 * D * 4 + 512)[ni & 31];
+            ids[rowid[b]] = id == NONE ? -1L : (long)id;
+            if (approx_out) {  // test hook: approximate distance of the winner and the gap to the runner-up
+                approx_out[2 * rowid[b]] = n1;
+                approx_out[2 * rowid[b] + 1] = n2 - n1;
+            }
+        }
+        if (collect) {
+            const unsigned long long flagged = __builtin_amdgcn_ballot_w64(mine && !unique);
+            if (flagged != 0) {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(&misc[1], (unsigned)__builtin_popcountll(flagged));
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                if (mine && !unique) {
+                    const unsigned rank = (unsigned)__builtin_popcountll(flagged & ((1ull << lane) - 1ull));
+                    amb_list[base + rank] = (uint32_t)pos;
+                }
+            }
+        }
+    }
+}
+
+// dist[i] = the contract's distance between row i and centroid ids[i] (same fmaf chains as the fp32
+// sweep: |x|^2, |c|^2 and the inner product in ascending feature order, (xn + cn) - 2 ip, clamped).
+template <int D>
+__global__ void __launch_bounds__(WG) exact_dist_rows_kernel(const float* __restrict__ X, long n,
+                                                             const float* __restrict__ C, int k,
+                                                             const long* __restrict__ ids,
+                                                             float* __restrict__ dist) {
+    const long i = (long)blockIdx.x * WG + threadIdx.x;
+    if (i >= n) return;
+    const long p = ids[i];
+    if (p < 0 || p >= k) {
+        dist[i] = __builtin_inff();
+        return;
+    }
+    const f32x4* px = reinterpret_cast<const f32x4*>(X + i * D);
+    const f32x4* pc = reinterpret_cast<const f32x4*>(C + p * D);
+    float xn = 0.0f, cn = 0.0f, ip = 0.0f;
+#pragma clang loop unroll(disable)
+    for (int q = 0; q < D / 4; q++) {
+        const f32x4 u = px[q], cu = pc[q];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            xn = __builtin_fmaf(u[e], u[e], xn);
+            cn = __builtin_fmaf(cu[e], cu[e], cn);
+            ip = __builtin_fmaf(cu[e], u[e], ip);
+        }
+    }
+    dist[i] = __builtin_fmaxf(__builtin_fmaf(-2.0f, ip, xn + cn), 0.0f);
+}
+
+// Same, in visiting order and reusing the pre-pass: where the winner is the guess, its distance is
+// the bd the pre-pass already evaluated with the very same chain.
+template <int D>
+__global__ void __launch_bounds__(WG) exact_dist_visit_kernel(const float* __restrict__ X, long n,
+                                                              const float* __restrict__ C, int k,
+                                                              const uint32_t* __restrict__ order,
+                                                              const uint32_t* __restrict__ hint_sorted,
+                                                              const float* __restrict__ bd,
+                                                              const long* __restrict__ ids,
+                                                              float* __restrict__ dist) {
+    const long pos = (long)blockIdx.x * WG + threadIdx.x;
+    if (pos >= n) return;
+    const long i = order[pos];
+    const long p = ids[i];
+    if (p < 0 || p >= k) {
+        dist[i] = __builtin_inff();
+        return;
+    }
+    if ((uint32_t)p == hint_sorted[pos]) {
+        dist[i] = bd[pos];
+        return;
+    }
+    const f32x4* px = reinterpret_cast<const f32x4*>(X + i * D);
+    const f32x4* pc = reinterpret_cast<const f32x4*>(C + p * D);
+    float xn = 0.0f, cn = 0.0f, ip = 0.0f;
+#pragma clang loop unroll(disable)
+    for (int q = 0; q < D / 4; q++) {
+        const f32x4 u = px[q], cu = pc[q];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            xn = __builtin_fmaf(u[e], u[e], xn);
+            cn = __builtin_fmaf(cu[e], cu[e], cn);
+            ip = __builtin_fmaf(cu[e], u[e], ip);
+        }
+    }
+    dist[i] = __builtin_fmaxf(__builtin_fmaf(-2.0f, ip, xn + cn), 0.0f);
+}
+
+// order_amb[i] = order[pos_i], hint_amb[i] = the filter's winner for that row (a very good guess)
+__global__ void __launch_bounds__(WG) gather_ambiguous_kernel(const uint32_t* __restrict__ pos_sorted, long m,
+                                                              long m_valid, const uint32_t* __restrict__ order,
+                                                              const long* __restrict__ ids,
+                                                              uint32_t* __restrict__ order_amb,
+                                                              uint32_t* __restrict__ hint_amb) {
+    const long i = (long)blockIdx.x * WG + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t pos = pos_sorted[i < m_valid ? i : m_valid - 1];  // padding repeats the last row
+    const uint32_t row = order[pos];
+    const long id = ids[row];
+    order_amb[i] = row;
+    hint_amb[i] = id >= 0 ? (uint32_t)id : NONE;
+}
+
+void filter_tau(int d, float* tau_a, float* tau_b) {
+    const double u = std::ldexp(1.0, -24);
+    const double q = std::sqrt((double)d) * std::ldexp(1.0, -25);
+    const double m = 3.0 * d / 16.0;
+    const double eps_h = 17.0 * m * u * 1.01 + 3.0 * std::ldexp(1.0, -23) + d * u * 1.01 + 2.0 * u + 2.0 * q;
+    const double delta_h = (2.0 * d + 8.0) * u * 1.01;
+    // rounded up generously when narrowed to float
+    *tau_a = (float)((2.0 * delta_h + 2.0 * eps_h) * 1.0001);
+    *tau_b = (float)(8.0 * q * 1.0001);
+}
+
+}  // namespace
+
+size_t at_filter_group_bytes(int d) { return group_bytes(d); }
+
+// Stage 1: image + sweep.  misc (device, 2 words) receives max|c|^2 and the number of listed rows;
+// amb_list receives their visiting positions (unordered).
+int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k, const uint32_t* order,
+                    const int32_t* cperm, int ng, const float* bd, const uint32_t* mask, int ngw, int collect,
+                    int64_t* ids, unsigned* misc, uint32_t* amb_list, float* approx_out, hipStream_t stream) {
+    unsigned char* img = static_cast<unsigned char*>(at_ws(ctx, WS_CENT_IMG16, group_bytes(d) * (size_t)ng, stream));
+    if (!img) return AT_E_NOMEM;
+    hipLaunchKernelGGL(prep_centroids_f16_kernel, dim3(ng), dim3(WG), 0, stream, c, k, d, cperm, img);
+    AT_LAUNCH_CHECK();
+    AT_HIP(hipMemsetAsync(misc, 0, 2 * sizeof(unsigned), stream));
+    hipLaunchKernelGGL(max_sqnorm_bits_kernel, dim3((k + WG - 1) / WG), dim3(WG), 0, stream, c, k, d, misc);
+    AT_LAUNCH_CHECK();
+    float ta = 0.0f, tb = 0.0f;
+    filter_tau(d, &ta, &tb);
+    constexpr int NB = 2;
+    const dim3 grid((unsigned)((n + 32 * NB - 1) / (32 * NB)));
+    // d = 128 would need 288 vector registers for two fragment sets: it stays on the fp32 sweep
+    AT_REQUIRE(d == 64, "at_filter_sweep: d must be 64");
+    hipLaunchKernelGGL((assign_f16filter_kernel<64, NB>), grid, dim3(64), 0, stream, x, (long)n, img, ng, order, bd,
+                       mask, ngw, misc, ta, tb, collect, reinterpret_cast<long*>(ids), amb_list, approx_out);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}
+
+int at_exact_dist_rows(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k, const int64_t* ids,
+                       float* dist, const uint32_t* order, const uint32_t* hint_sorted, const float* bd,
+                       hipStream_t stream) {
+    (void)ctx;
+    const dim3 grid((unsigned)((n + WG - 1) / WG));
+    if (order && hint_sorted && bd) {  // guesses with their pre-pass distances available
+        if (d == 64)
+            hipLaunchKernelGGL(exact_dist_visit_kernel<64>, grid, dim3(WG), 0, stream, x, (long)n, c, k, order,
+                               hint_sorted, bd, reinterpret_cast<const long*>(ids), dist);
+        else
+            hipLaunchKernelGGL(exact_dist_visit_kernel<128>, grid, dim3(WG), 0, stream, x, (long)n, c, k, order,
+                               hint_sorted, bd, reinterpret_cast<const long*>(ids), dist);
+        AT_LAUNCH_CHECK();
+        return AT_OK;
+    }
+    if (d == 64)
+        hipLaunchKernelGGL(exact_dist_rows_kernel<64>, grid, dim3(WG), 0, stream, x, (long)n, c, k,
+                           reinterpret_cast<const long*>(ids), dist);
+    else
+        hipLaunchKernelGGL(exact_dist_rows_kernel<128>, grid, dim3(WG), 0, stream, x, (long)n, c, k,
+                           reinterpret_cast<const long*>(ids), dist);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}
+
+// Sorts the m_valid listed positions (visiting order keeps the tiles of the redo pass coherent) and
+// expands them to m >= m_valid entries (the fp32 sweep wants at least 20 rows).
+int at_filter_gather_ambiguous(at_ctx* ctx, uint32_t* amb_list, uint32_t* amb_sorted, int64_t m_valid, int64_t m,
+                               const uint32_t* order, const int64_t* ids, uint32_t* order_amb, uint32_t* hint_amb,
+                               hipStream_t stream) {
+    size_t tmp_bytes = 0;
+    AT_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, amb_list, amb_sorted, (size_t)m_valid, 0, 32, stream));
+    void* tmp = at_ws(ctx, WS_SORT_TMP, tmp_bytes, stream);
+    if (!tmp) return AT_E_NOMEM;
+    AT_HIP(rocprim::radix_sort_keys(tmp, tmp_bytes, amb_list, amb_sorted, (size_t)m_valid, 0, 32, stream));
+    hipLaunchKernelGGL(gather_ambiguous_kernel, dim3((unsigned)((m + WG - 1) / WG)), dim3(WG), 0, stream, amb_sorted,
+                       (long)m, (long)m_valid, order, reinterpret_cast<const long*>(ids), order_amb, hint_amb);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}
