@@ -1288,7 +1288,16 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
         AT_HIP(hipStreamSynchronize(stream));
         ctx->filter_rows += n;
         ctx->filter_listed += listed;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ctx->filter_ev[0], ctx->filter_ev[1]) == hipSuccess) {
+            ctx->filter_ms += ms;
+            ctx->filter_launches++;
+        }
         if (listed == 0) return AT_OK;
+        // short lists: one workgroup per row on the vector ALU; long ones (badly conditioned data,
+        // centroids outside the fp16 range): the fp32 MFMA sweep over the listed rows
+        if ((int64_t)listed * 16 <= n)
+            return at_filter_redo_rows(ctx, x, D, c, k, list, listed, order, cperm, dmin, ng, misc, ids, dist, stream);
         n2 = listed < 64 ? 64 : (int64_t)listed;
         uint32_t* sorted = list + ((size_t)n + 64);
         uint32_t* order_amb = sorted + ((size_t)n + 64);
@@ -1358,11 +1367,17 @@ extern "C" int at_prune_mask_f32(at_ctx* ctx, const float* x, int64_t n, int d, 
 }
 
 // fp16-split filter: rows swept / rows handed to the fp32 redo since the last reset.
-extern "C" int at_filter_stats(at_ctx* ctx, int64_t* rows, int64_t* listed, int reset) {
+extern "C" int at_filter_stats(at_ctx* ctx, int64_t* rows, int64_t* listed, double* sweep_ms, int64_t* sweeps,
+                               int reset) {
     AT_REQUIRE(ctx && rows && listed, "at_filter_stats: bad arguments");
     *rows = ctx->filter_rows;
     *listed = ctx->filter_listed;
-    if (reset) ctx->filter_rows = ctx->filter_listed = 0;
+    if (sweep_ms) *sweep_ms = ctx->filter_ms;
+    if (sweeps) *sweeps = ctx->filter_launches;
+    if (reset) {
+        ctx->filter_rows = ctx->filter_listed = ctx->filter_launches = 0;
+        ctx->filter_ms = 0.0;
+    }
     return AT_OK;
 }
 

@@ -38,6 +38,9 @@ struct at_ctx {
     const float* fb_user;
     int rs_orig, rs_new;  // what WS_RESAMPLE_TAPS currently holds
     int64_t filter_rows, filter_listed;  // fp16-split filter: rows swept / rows handed to the fp32 redo
+    hipEvent_t filter_ev[2];             // around the stage-1 kernel of exact calls (created on first use)
+    double filter_ms;                    // summed stage-1 kernel time, over filter_launches launches
+    int64_t filter_launches;
 };
 
 int at_fail(int code, const char* fmt, ...);
@@ -75,5 +78,9 @@ int at_exact_dist_rows(at_ctx* ctx, const float* x, int64_t n, int d, const floa
 int at_filter_gather_ambiguous(at_ctx* ctx, uint32_t* amb_list, uint32_t* amb_sorted, int64_t m_valid, int64_t m,
                                const uint32_t* order, const int64_t* ids, uint32_t* order_amb, uint32_t* hint_amb,
                                hipStream_t stream);
+
+int at_filter_redo_rows(at_ctx* ctx, const float* x, int d, const float* c, int k, const uint32_t* list, int64_t m,
+                        const uint32_t* order, const int32_t* cperm, const float* dmin, int ng, const unsigned* misc,
+                        int64_t* ids, float* dist, hipStream_t stream);
 
 static inline bool at_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -372,6 +372,103 @@ __global__ void __launch_bounds__(WG) gather_ambiguous_kernel(const uint32_t* __
     hint_amb[i] = id >= 0 ? (uint32_t)id : NONE;
 }
 
+// Redo of ONE listed row per workgroup, on the vector ALU: the row's own Elkan test (the per-row
+// criterion of prune_mask_kernel, with the filter's winner as the guess) picks the groups, every
+// thread evaluates the contract's distance (the same three fmaf chains as everywhere else) for a few
+// of their centroids, and the workgroup reduces lexicographically by (distance, index).  A few
+// microseconds per row whatever the neighbours in its tile need -- the MFMA sweep on a sparse list
+// of rows spends its time walking unions of groups instead.
+template <int D>
+__global__ void __launch_bounds__(WG) exact_rows_kernel(const float* __restrict__ X, const float* __restrict__ C, int k,
+                                                        const uint32_t* __restrict__ list,
+                                                        const uint32_t* __restrict__ order,
+                                                        const int32_t* __restrict__ cperm,
+                                                        const float* __restrict__ dmin, int ng,
+                                                        const unsigned* __restrict__ misc, long* __restrict__ ids,
+                                                        float* __restrict__ dist) {
+    __shared__ int needed[512];
+    __shared__ int n_needed;
+    __shared__ float red_d[WG / 64];
+    __shared__ unsigned red_i[WG / 64];
+    const int tid = threadIdx.x;
+    const long row = order[list[blockIdx.x]];
+    const long p = ids[row];
+    const bool has = p >= 0 && p < k;
+    f32x4 xv[D / 4];
+    const f32x4* px = reinterpret_cast<const f32x4*>(X + row * D);
+#pragma unroll
+    for (int q = 0; q < D / 4; q++) xv[q] = px[q];
+    float xn = 0.0f;
+#pragma unroll
+    for (int q = 0; q < D / 4; q++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) xn = __builtin_fmaf(xv[q][e], xv[q][e], xn);
+    auto contract_dist = [&](long cid) {
+        const f32x4* pc = reinterpret_cast<const f32x4*>(C + cid * D);
+        float cn = 0.0f, ip = 0.0f;
+#pragma unroll
+        for (int q = 0; q < D / 4; q++) {
+            const f32x4 cu = pc[q];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                cn = __builtin_fmaf(cu[e], cu[e], cn);
+                ip = __builtin_fmaf(cu[e], xv[q][e], ip);
+            }
+        }
+        return __builtin_fmaxf(__builtin_fmaf(-2.0f, ip, xn + cn), 0.0f);
+    };
+    float tau = __builtin_inff();
+    if (has) {
+        const float dh = contract_dist(p);
+        const float cnmax = __uint_as_float(misc[0]);
+        const float delta = (2.0f * D + 8.0f) * 5.9604645e-8f * (xn + cnmax) * 1.01f;
+        tau = 2.0f * sqrtf(dh + delta) * (1.0f + 4.0f * 5.9604645e-8f) + 1e-30f;
+        if (!(tau == tau)) tau = __builtin_inff();  // non-finite row: look everywhere
+    }
+    if (tid == 0) n_needed = 0;
+    __syncthreads();
+    for (int g = tid; g < ng; g += WG) {
+        const bool need = !has || dmin[(size_t)p * ng + g] <= tau;
+        if (need) needed[atomicAdd(&n_needed, 1)] = g;
+    }
+    __syncthreads();
+    const int items = n_needed * 32;
+    float bd = __builtin_inff();
+    unsigned bi = NONE;
+    for (int w = tid; w < items; w += WG) {
+        const int cid = cperm[needed[w >> 5] * 32 + (w & 31)];
+        if (cid < 0 || cid >= k) continue;
+        const float dd = contract_dist(cid);
+        if (dd < bd || (dd == bd && (unsigned)cid < bi)) {
+            bd = dd;
+            bi = (unsigned)cid;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float od = __shfl_xor(bd, off);
+        const unsigned oi = (unsigned)__shfl_xor((int)bi, off);
+        if (od < bd || (od == bd && oi < bi)) {
+            bd = od;
+            bi = oi;
+        }
+    }
+    if ((tid & 63) == 0) {
+        red_d[tid >> 6] = bd;
+        red_i[tid >> 6] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < WG / 64; w++)
+            if (red_d[w] < bd || (red_d[w] == bd && red_i[w] < bi)) {
+                bd = red_d[w];
+                bi = red_i[w];
+            }
+        ids[row] = bi == NONE ? -1L : (long)bi;
+        if (dist) dist[row] = bd;
+    }
+}
+
 void filter_tau(int d, float* tau_a, float* tau_b) {
     const double u = std::ldexp(1.0, -24);
     const double q = std::sqrt((double)d) * std::ldexp(1.0, -25);
@@ -405,9 +502,15 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
     const dim3 grid((unsigned)((n + 32 * NB - 1) / (32 * NB)));
     // d = 128 would need 288 vector registers for two fragment sets: it stays on the fp32 sweep
     AT_REQUIRE(d == 64, "at_filter_sweep: d must be 64");
+    if (collect) {  // exact calls synchronise anyway: time the kernel for at_filter_stats
+        for (int i = 0; i < 2; i++)
+            if (!ctx->filter_ev[i]) AT_HIP(hipEventCreate(&ctx->filter_ev[i]));
+        AT_HIP(hipEventRecord(ctx->filter_ev[0], stream));
+    }
     hipLaunchKernelGGL((assign_f16filter_kernel<64, NB>), grid, dim3(64), 0, stream, x, (long)n, img, ng, order, bd,
                        mask, ngw, misc, ta, tb, collect, reinterpret_cast<long*>(ids), amb_list, approx_out);
     AT_LAUNCH_CHECK();
+    if (collect) AT_HIP(hipEventRecord(ctx->filter_ev[1], stream));
     return AT_OK;
 }
 
@@ -448,6 +551,24 @@ int at_filter_gather_ambiguous(at_ctx* ctx, uint32_t* amb_list, uint32_t* amb_so
     AT_HIP(rocprim::radix_sort_keys(tmp, tmp_bytes, amb_list, amb_sorted, (size_t)m_valid, 0, 32, stream));
     hipLaunchKernelGGL(gather_ambiguous_kernel, dim3((unsigned)((m + WG - 1) / WG)), dim3(WG), 0, stream, amb_sorted,
                        (long)m, (long)m_valid, order, reinterpret_cast<const long*>(ids), order_amb, hint_amb);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}
+
+
+// Stage 2 for short lists: one workgroup per listed row (see exact_rows_kernel).
+int at_filter_redo_rows(at_ctx* ctx, const float* x, int d, const float* c, int k, const uint32_t* list, int64_t m,
+                        const uint32_t* order, const int32_t* cperm, const float* dmin, int ng, const unsigned* misc,
+                        int64_t* ids, float* dist, hipStream_t stream) {
+    (void)ctx;
+    if (m <= 0) return AT_OK;
+    AT_REQUIRE(ng <= 512, "at_filter_redo_rows: ng > 512");
+    if (d == 64)
+        hipLaunchKernelGGL(exact_rows_kernel<64>, dim3((unsigned)m), dim3(WG), 0, stream, x, c, k, list, order, cperm, dmin,
+                           ng, misc, reinterpret_cast<long*>(ids), dist);
+    else
+        hipLaunchKernelGGL(exact_rows_kernel<128>, dim3((unsigned)m), dim3(WG), 0, stream, x, c, k, list, order, cperm,
+                           dmin, ng, misc, reinterpret_cast<long*>(ids), dist);
     AT_LAUNCH_CHECK();
     return AT_OK;
 }

@@ -61,6 +61,8 @@ void at_destroy(at_ctx* ctx) {
     (void)hipDeviceSynchronize();
     for (int i = 0; i < WS_NSLOTS; i++)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+    for (int i = 0; i < 2; i++)
+        if (ctx->filter_ev[i]) (void)hipEventDestroy(ctx->filter_ev[i]);
     (void)hipSetDevice(prev);
     delete ctx;
 }

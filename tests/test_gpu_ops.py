@@ -112,9 +112,12 @@ def test_assign_pruned_is_exact(be, oracle, monkeypatch, n, d, k, lds_kernel):
     }
     for name, (hint, hd) in cases.items():
         order = be.visit_order(hint.contiguous(), hd, k)
-        ids, dis = be.assign_pruned(xt, ct, order, cperm, dmin)
-        assert np.array_equal(ids.cpu().numpy(), ids_o), f"hint={name}: {(ids.cpu().numpy() != ids_o).sum()} ids differ"
-        assert np.array_equal(bits(dis.cpu().numpy()), bits(dis_o)), name
+        for flt in ((False, True) if d == 64 else (False,)):       # fp32 sweep alone / behind the fp16-split filter
+            ids, dis = be.assign_pruned(xt, ct, order, cperm, dmin, filter=flt)
+            assert np.array_equal(ids.cpu().numpy(), ids_o), f"hint={name} filter={flt}: {(ids.cpu().numpy() != ids_o).sum()} ids differ"
+            assert np.array_equal(bits(dis.cpu().numpy()), bits(dis_o)), (name, flt)
+            ids, none = be.assign_pruned(xt, ct, order, cperm, dmin, want_dist=False, filter=flt)
+            assert none is None and np.array_equal(ids.cpu().numpy(), ids_o), (name, flt)
     # unguided coarse-to-fine search: same answer again
     ids, dis = be.assign_c2f(xt, ct, cperm, dmin)
     assert np.array_equal(ids.cpu().numpy(), ids_o) and np.array_equal(bits(dis.cpu().numpy()), bits(dis_o))
@@ -124,6 +127,91 @@ def test_assign_pruned_is_exact(be, oracle, monkeypatch, n, d, k, lds_kernel):
     assert np.array_equal(np.sort(o), np.arange(n))
     assert np.array_equal(hs.cpu().numpy().view(np.uint32), ids_o[o].astype(np.uint32))
     assert (np.diff(ids_o[o]) >= 0).all()
+
+
+def _filter_eps(d, H):
+    """The a-priori bound of csrc/filter.hip on |P16 + |x|^2 - true squared distance| (header there)."""
+    u, q, m = 2.0 ** -24, np.sqrt(d) * 2.0 ** -25, 3.0 * d / 16.0
+    return H * (17 * m * u * 1.01 + 3 * 2.0 ** -23 + d * u * 1.01 + 2 * u + 2 * q) + 4 * q
+
+
+@pytest.mark.parametrize("scale_x,scale_c", [(1.0, 1.0), (30.0, 0.02), (0.003, 7.0), (1000.0, 1000.0)])
+def test_filter_error_bound(be, oracle, scale_x, scale_c):
+    """Stage 1 alone: the approximate distances stay inside the bound the acceptance test assumes
+    (measured against float64), on unit rows and on badly scaled ones, with sign-alternating data
+    that makes the inner products cancel."""
+    rng = np.random.default_rng(17)
+    n, d, k = 40000, 64, 2048
+    x = (rng.standard_normal((n, d)) * rng.choice([1e-3, 1.0], (n, d), p=[0.3, 0.7])).astype(np.float32)
+    x = oracle.l2norm_rows(x) * np.float32(scale_x)
+    c = oracle.l2norm_rows((x[rng.integers(0, n, k)] / np.float32(scale_x) + 0.02 * rng.standard_normal((k, d))).astype(np.float32))
+    c = (c * np.float32(scale_c)).astype(np.float32)
+    xt, ct = be._f32(x), be._f32(c)
+    ids_o, dis_o = oracle.assign(x, c)
+    cperm = be.from_host(be.group_rows_kd(c))
+    dmin = be.group_min_dist(ct, cperm)
+    order = be.visit_order(torch.from_numpy(ids_o).to(be.device), torch.from_numpy(dis_o).to(be.device), k)
+    win, approx, listed = be.filter_probe(xt, ct, order, cperm, dmin)
+    win, approx = win.cpu().numpy(), approx.cpu().numpy().astype(np.float64)
+    ok = win >= 0
+    assert ok.mean() > 0.99
+    x64, c64 = x.astype(np.float64), c.astype(np.float64)
+    P_true = (c64[win[ok]] ** 2).sum(1) - 2.0 * (x64[ok] * c64[win[ok]]).sum(1)
+    H = (x64[ok] ** 2).sum(1) + (c64 ** 2).sum(1).max()
+    err = np.abs(approx[ok, 0] - P_true)
+    eps = _filter_eps(d, H)
+    assert (err <= eps).all(), f"max err/eps {np.max(err / eps):.3f}"
+    assert np.max(err / eps) < 0.25           # the budget is meant to be generous
+    # rows whose stage-1 winner is not the contract's arg-min must all have been listed
+    assert (win != ids_o).sum() <= listed
+    ids, dis = be.assign_pruned(xt, ct, order, cperm, dmin, filter=True)
+    assert np.array_equal(ids.cpu().numpy(), ids_o) and np.array_equal(bits(dis.cpu().numpy()), bits(dis_o))
+
+
+def test_filter_near_ties_and_bad_values(be, oracle):
+    """Rows engineered to sit exactly on, and within 1e-7 ... 1e-3 of, the bisector of two centroids;
+    duplicated centroids; a row and a centroid outside the fp16 range; a NaN row: always the fp32
+    contract's answer."""
+    rng = np.random.default_rng(23)
+    n, d, k = 30000, 64, 1024
+    c = _unit_rows(rng, k, d, oracle)
+    c[700:720] = c[100:120]                                        # exact duplicates
+    a, b = rng.integers(0, k, n), rng.integers(0, k, n)
+    t = np.float32(0.5) + rng.choice([0.0, 1e-7, -1e-7, 1e-6, -1e-5, 1e-4, -1e-3], n).astype(np.float32)
+    x = (c[a] * t[:, None] + c[b] * (np.float32(1) - t)[:, None] + 0.002 * rng.standard_normal((n, d))).astype(np.float32)
+    x[:2000] = (c[a[:2000]] * np.float32(0.5) + c[b[:2000]] * np.float32(0.5)).astype(np.float32)   # exact midpoints
+    x[2000:2100] = c[rng.integers(0, k, 100)]                      # rows equal to centroids
+    for label in ("plain", "big_row", "big_centroid", "nan_row"):
+        xx, cc = x.copy(), c.copy()
+        if label == "big_row":
+            xx[5, 3] = 70000.0
+        if label == "big_centroid":
+            cc[9, 1] = 40000.0
+        if label == "nan_row":
+            xx[7, 0] = np.nan
+        xt, ct = be._f32(xx), be._f32(cc)
+        ids_d, dis_d = be.assign(xt, ct)                            # dense fp32 sweep (pinned to the oracle elsewhere)
+        if label == "plain":
+            ids_o, dis_o = oracle.assign(xx, cc)
+            assert np.array_equal(ids_d.cpu().numpy(), ids_o) and np.array_equal(bits(dis_d.cpu().numpy()), bits(dis_o))
+        cperm = be.from_host(be.group_rows_kd(cc))
+        dmin = be.group_min_dist(ct, cperm)
+        for hint in (ids_d, torch.from_numpy(a).to(be.device), torch.full((n,), -1, dtype=torch.int64, device=be.device)):
+            order = be.visit_order(hint.contiguous(), None, k)
+            be.filter_stats()
+            ids, dis = be.assign_pruned(xt, ct, order, cperm, dmin, filter=True)
+            rows, listed = be.filter_stats()
+            assert rows == n and 0 < listed <= n
+            if label == "big_centroid":
+                assert listed == n                                   # the whole call falls back to fp32
+            same = ids == ids_d
+            if label == "nan_row":                                   # a NaN row has no defined winner
+                same[7] = True
+            assert bool(same.all()), label
+            keep = torch.ones(n, dtype=torch.bool, device=be.device)
+            if label == "nan_row":
+                keep[7] = False
+            assert torch.equal(dis[keep].view(torch.int32), dis_d[keep].view(torch.int32)), label
 
 
 @pytest.mark.parametrize("n", [1, 5, 19])
