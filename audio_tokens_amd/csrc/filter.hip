@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(64, 2)
 assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char* __restrict__ img, int ng,
                         const uint32_t* __restrict__ order, const float* __restrict__ bd_in,
                         const uint32_t* __restrict__ mask, int ngw, unsigned* __restrict__ misc, float tau_a,
-                        float tau_b, int collect, long* __restrict__ ids, uint32_t* __restrict__ amb_list,
+                        float tau_b, float rho_a, float rho_b, int screen, int collect, long* __restrict__ ids, uint32_t* __restrict__ amb_list,
                         float* __restrict__ approx_out) {
     constexpr int NS = D / 16;
     constexpr int MAXW = 16;
@@ -116,7 +116,7 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
     const bool c_bad = !(cnmax < RANGE_SQ);
 
     half8 xh[NB][NS], xl[NB][NS];
-    float b1[NB], b2[NB], tau[NB];
+    float b1[NB], b2[NB], tau[NB], rho[NB];
     unsigned i1[NB];
     bool bad[NB];
     long rowid[NB];
@@ -149,6 +149,7 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
         }
         const float nrm = part + __shfl_xor(part, 32);
         tau[b] = __builtin_fmaf(tau_a, nrm * 1.001f + cnmax, tau_b);
+        rho[b] = screen ? __builtin_fmaf(rho_a, nrm * 1.001f + cnmax, rho_b) : __builtin_inff();
         bad[b] = c_bad || !(nrm < RANGE_SQ);
         const float bd = bd_in[pos];
         // candidates above the cap can neither be the arg-min nor within tau of it: the guess itself
@@ -191,36 +192,59 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
         return g < ng ? g : ng;
     };
 
-    auto load_group = [&](int g, half8 (&ah)[NS], half8 (&al)[NS], f32x4 (&cn)[4]) {
+    // The hi*hi product alone is within rho of the three-term value: a tile in which no row's hi*hi
+    // distance comes within rho of that row's runner-up cannot change anybody's (best, runner-up)
+    // pair, so its two lo products (8 of the 12 MFMAs) are skipped and the lo fragments of the group
+    // are fetched only when some tile asks for them.
+    auto load_group = [&](int g, half8 (&ah)[NS], f32x4 (&cn)[4]) {
         const unsigned char* base = img + (size_t)g * GB;
         const half8* fr = reinterpret_cast<const half8*>(base);
 #pragma unroll
-        for (int s = 0; s < NS; s++) {
-            ah[s] = fr[(2 * s + 0) * 64 + lane];
-            al[s] = fr[(2 * s + 1) * 64 + lane];
-        }
+        for (int s = 0; s < NS; s++) ah[s] = fr[(2 * s + 0) * 64 + lane];
         const float* cnp = reinterpret_cast<const float*>(base + (size_t)32 * D * 4);
 #pragma unroll
         for (int q = 0; q < 4; q++) cn[q] = *reinterpret_cast<const f32x4*>(cnp + 8 * q + 4 * h);
     };
-    auto compute_group = [&](int g, const half8 (&ah)[NS], const half8 (&al)[NS], const f32x4 (&cnv)[4]) {
+    auto compute_group = [&](int g, const half8 (&ah)[NS], const f32x4 (&cnv)[4]) {
         const uint32_t gbit = 1u << (g & 31);
+        f32x16 acc[NB];
+        bool pass[NB];
+        bool anypass = false;
 #pragma unroll
         for (int b = 0; b < NB; b++) {
+            pass[b] = false;
             if ((word_of(mw[b], g >> 5) & gbit) == 0u) continue;  // wave-uniform
-            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            f32x16 a = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < NS; s++) a = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[b][s], a, 0, 0, 0);
+            float m = __builtin_inff();
+#pragma unroll
+            for (int r = 0; r < 16; r++) m = __builtin_fminf(m, __builtin_fmaf(-2.0f, a[r], cnv[r >> 2][r & 3]));
+            acc[b] = a;
+            pass[b] = __builtin_amdgcn_ballot_w64(m < b2[b] + rho[b]) != 0;
+            anypass |= pass[b];
+        }
+        if (!anypass) return;
+        half8 al[NS];
+        {
+            const half8* fr = reinterpret_cast<const half8*>(img + (size_t)g * GB);
+#pragma unroll
+            for (int s = 0; s < NS; s++) al[s] = fr[(2 * s + 1) * 64 + lane];
+        }
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            if (!pass[b]) continue;  // wave-uniform
+            f32x16 a = acc[b];
 #pragma unroll
             for (int s = 0; s < NS; s++) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], xh[b][s], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xl[b][s], acc, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], xh[b][s], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xl[b][s], a, 0, 0, 0);
             }
-#pragma unroll
-            for (int s = 0; s < NS; s++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[b][s], acc, 0, 0, 0);
             float P[16];
             float m = __builtin_inff();
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                P[r] = __builtin_fmaf(-2.0f, acc[r], cnv[r >> 2][r & 3]);
+                P[r] = __builtin_fmaf(-2.0f, a[r], cnv[r >> 2][r & 3]);
                 m = __builtin_fminf(m, P[r]);
             }
             if (__builtin_amdgcn_ballot_w64(m < b2[b]) != 0) {
@@ -240,18 +264,18 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
         }
     };
 
-    half8 ahA[NS], alA[NS], ahB[NS], alB[NS];
+    half8 ahA[NS], ahB[NS];
     f32x4 cnA[4], cnB[4];
     int g = next_group(0);
-    if (g < ng) load_group(g, ahA, alA, cnA);
+    if (g < ng) load_group(g, ahA, cnA);
     while (g < ng) {
         const int g1 = next_group(g + 1);
-        if (g1 < ng) load_group(g1, ahB, alB, cnB);
-        compute_group(g, ahA, alA, cnA);
+        if (g1 < ng) load_group(g1, ahB, cnB);
+        compute_group(g, ahA, cnA);
         if (g1 >= ng) break;
         const int g2 = next_group(g1 + 1);
-        if (g2 < ng) load_group(g2, ahA, alA, cnA);
-        compute_group(g1, ahB, alB, cnB);
+        if (g2 < ng) load_group(g2, ahA, cnA);
+        compute_group(g1, ahB, cnB);
         g = g2;
     }
 
@@ -480,6 +504,18 @@ void filter_tau(int d, float* tau_a, float* tau_b) {
     *tau_b = (float)(8.0 * q * 1.0001);
 }
 
+// |P(three terms) - P(hi*hi only)| <= rho_a (|x|^2 + max|c|^2) + rho_b: the two lo products are at most
+// 2^-10 * 1.001 s t + q (s + t) (fp16 rounding of the hi parts), accumulating them takes 2 (d/16) MFMAs
+// (17 roundings of 2u of the running magnitude each), the fma that forms P rounds once; doubled for
+// the factor -2, with s t <= H / 2 and s + t <= 1 + H / 2.
+void filter_rho(int d, float* rho_a, float* rho_b) {
+    const double u = std::ldexp(1.0, -24);
+    const double q = std::sqrt((double)d) * std::ldexp(1.0, -25);
+    const double m = 2.0 * d / 16.0;
+    *rho_a = (float)((std::ldexp(1.0, -10) * 1.001 + 34.0 * m * u * 1.01 + 2.0 * u + q) * 1.0001);
+    *rho_b = (float)(2.0 * q * 1.0001);
+}
+
 }  // namespace
 
 size_t at_filter_group_bytes(int d) { return group_bytes(d); }
@@ -496,8 +532,11 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
     AT_HIP(hipMemsetAsync(misc, 0, 2 * sizeof(unsigned), stream));
     hipLaunchKernelGGL(max_sqnorm_bits_kernel, dim3((k + WG - 1) / WG), dim3(WG), 0, stream, c, k, d, misc);
     AT_LAUNCH_CHECK();
-    float ta = 0.0f, tb = 0.0f;
+    float ta = 0.0f, tb = 0.0f, ra = 0.0f, rb = 0.0f;
     filter_tau(d, &ta, &tb);
+    filter_rho(d, &ra, &rb);
+    const char* sc = std::getenv("AT_FILTER_SCREEN");  // A/B aid: 0 = always evaluate all three products
+    const int screen = (sc && std::atoi(sc) == 0) ? 0 : 1;
     constexpr int NB = 2;
     const dim3 grid((unsigned)((n + 32 * NB - 1) / (32 * NB)));
     // d = 128 would need 288 vector registers for two fragment sets: it stays on the fp32 sweep
@@ -508,7 +547,7 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
         AT_HIP(hipEventRecord(ctx->filter_ev[0], stream));
     }
     hipLaunchKernelGGL((assign_f16filter_kernel<64, NB>), grid, dim3(64), 0, stream, x, (long)n, img, ng, order, bd,
-                       mask, ngw, misc, ta, tb, collect, reinterpret_cast<long*>(ids), amb_list, approx_out);
+                       mask, ngw, misc, ta, tb, ra, rb, screen, collect, reinterpret_cast<long*>(ids), amb_list, approx_out);
     AT_LAUNCH_CHECK();
     if (collect) AT_HIP(hipEventRecord(ctx->filter_ev[1], stream));
     return AT_OK;
