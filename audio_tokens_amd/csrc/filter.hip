@@ -46,10 +46,14 @@ constexpr unsigned NONE = 0xffffffffu;
 constexpr float RANGE_SQ = 1073741824.0f;  // 2^30: |v| < 2^15 for every component
 
 __host__ __device__ constexpr size_t group_bytes(int d) { return (size_t)32 * d * 4 + 1024; }
+__host__ __device__ constexpr size_t misc_off(int d) { return (size_t)(d / 16) * 1024; }   // |c|^2, +128: indices
+__host__ __device__ constexpr size_t lo_off(int d) { return (size_t)(d / 16) * 1024 + 1024; }
 
-// Image of group g: fragments [s = feature/16][hi, lo][lane][8 halves] (lane = 32 * ((f % 16) / 8) +
-// slot, exactly the A operand of v_mfma_f32_32x32x16_f16, one coalesced 1 KiB load per fragment),
-// then |c|^2 of the 32 slots (+inf for padding) and, 512 bytes further, their centroid indices.
+// Image of group g, hot part first: hi fragments [s = feature/16][lane][8 halves] (lane = 32 * ((f % 16)
+// / 8) + slot, exactly the A operand of v_mfma_f32_32x32x16_f16, 1 KiB per fragment), then 256 bytes of
+// |c|^2 of the 32 slots (+inf for padding) and their centroid indices (padded to 1 KiB), then the lo
+// fragments in the same form.  The sweep streams the first d/16 KiB + 256 B of every group it
+// visits and touches the lo fragments of a few.
 __global__ void __launch_bounds__(WG) prep_centroids_f16_kernel(const float* __restrict__ c, int k, int d,
                                                                 const int32_t* __restrict__ cperm,
                                                                 unsigned char* __restrict__ img) {
@@ -63,11 +67,11 @@ __global__ void __launch_bounds__(WG) prep_centroids_f16_kernel(const float* __r
         const _Float16 hi = (_Float16)v;
         const _Float16 lo = (_Float16)(v - (float)hi);
         const int s = f >> 4, lane = 32 * ((f & 15) >> 3) + i, el = f & 7;
-        frag[((size_t)(2 * s + 0) * 64 + lane) * 8 + el] = hi;
-        frag[((size_t)(2 * s + 1) * 64 + lane) * 8 + el] = lo;
+        frag[((size_t)s * 64 + lane) * 8 + el] = hi;
+        reinterpret_cast<_Float16*>(out + lo_off(d))[((size_t)s * 64 + lane) * 8 + el] = lo;
     }
-    float* cn = reinterpret_cast<float*>(out + (size_t)32 * d * 4);
-    unsigned* idx = reinterpret_cast<unsigned*>(out + (size_t)32 * d * 4 + 512);
+    float* cn = reinterpret_cast<float*>(out + misc_off(d));
+    unsigned* idx = reinterpret_cast<unsigned*>(out + misc_off(d) + 128);
     for (int i = threadIdx.x; i < 32; i += WG) {
         const int row = cperm[g * 32 + i];
         float nrm = __builtin_inff();
@@ -93,19 +97,35 @@ __global__ void __launch_bounds__(WG) max_sqnorm_bits_kernel(const float* __rest
     atomicMax(out_bits, __float_as_uint(s) & 0x7fffffffu);
 }
 
-// One wavefront per workgroup, structure of assign_mfma_pruned_reg_kernel (assign.hip): the wave
-// walks the groups its 32*NB rows need, the fragments of the next group are fetched into registers
-// while the current one multiplies.  misc[0] = max |c|^2 bits, misc[1] = ambiguous-row counter.
+// One wavefront per workgroup, the structure of assign_mfma_pruned_reg_kernel (assign.hip): the wave
+// walks the groups its 64 rows (two 32-row tiles) need; the hi fragments of the next group are
+// fetched into registers while the current one multiplies.  The needed groups are compacted once
+// into a small LDS list (group | tile bits), so the walk costs a handful of scalar instructions per
+// group.  misc[0] = max |c|^2 bits, misc[1] = ambiguous-row counter.
+//
+// The hi*hi product alone is within rho of the three-term value: a tile in which no row's hi*hi
+// distance comes within rho of that row's runner-up cannot change anybody's (best, runner-up)
+// pair, so its two lo products (8 of the 12 MFMAs) are skipped and the lo fragments of the group
+// are fetched only when some tile asks for them.
+__device__ __forceinline__ float min16(const float (&p)[16]) {
+    const float a = __builtin_fminf(__builtin_fminf(p[0], p[1]), __builtin_fminf(p[2], p[3]));
+    const float b = __builtin_fminf(__builtin_fminf(p[4], p[5]), __builtin_fminf(p[6], p[7]));
+    const float c = __builtin_fminf(__builtin_fminf(p[8], p[9]), __builtin_fminf(p[10], p[11]));
+    const float d = __builtin_fminf(__builtin_fminf(p[12], p[13]), __builtin_fminf(p[14], p[15]));
+    return __builtin_fminf(__builtin_fminf(a, b), __builtin_fminf(c, d));
+}
+
 template <int D, int NB>
 __global__ void __launch_bounds__(64, 2)
 assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char* __restrict__ img, int ng,
                         const uint32_t* __restrict__ order, const float* __restrict__ bd_in,
                         const uint32_t* __restrict__ mask, int ngw, unsigned* __restrict__ misc, float tau_a,
-                        float tau_b, float rho_a, float rho_b, int screen, int collect, long* __restrict__ ids, uint32_t* __restrict__ amb_list,
-                        float* __restrict__ approx_out) {
+                        float tau_b, float rho_a, float rho_b, int screen, int collect, long* __restrict__ ids,
+                        uint32_t* __restrict__ amb_list, float* __restrict__ approx_out) {
+    static_assert(NB == 2, "written for two 32-row tiles per wave");
     constexpr int NS = D / 16;
-    constexpr int MAXW = 16;
     constexpr size_t GB = group_bytes(D);
+    __shared__ unsigned short glist[512];
 
     const int lane = threadIdx.x;
     const int j = lane & 31;
@@ -120,7 +140,6 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
     unsigned i1[NB];
     bool bad[NB];
     long rowid[NB];
-    uint32_t mw[NB][MAXW];
 #pragma unroll
     for (int b = 0; b < NB; b++) {
         long pos = pos0 + 32 * b + j;
@@ -158,125 +177,122 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
         b1[b] = cap;
         b2[b] = cap;
         i1[b] = NONE;
-        const long tile = pos0 / 32 + b;
-#pragma unroll
-        for (int w = 0; w < MAXW; w++) {
-            uint32_t m = 0;
-            if (w < ngw && tile < ntile32) m = mask[(size_t)tile * ngw + w];
-            mw[b][w] = __builtin_amdgcn_readfirstlane(m);
-        }
     }
-    uint32_t any[MAXW];
-#pragma unroll
-    for (int w = 0; w < MAXW; w++) {
-        any[w] = 0;
-#pragma unroll
-        for (int b = 0; b < NB; b++) any[w] |= mw[b][w];
-    }
-    auto word_of = [&](const uint32_t (&m)[MAXW], int w) -> uint32_t {
-        uint32_t v = 0;
-#pragma unroll
-        for (int i = 0; i < MAXW; i++)
-            if (i == w) v = m[i];
-        return v;
-    };
-    auto next_group = [&](int from) {
-        int w = from >> 5;
-        if (w >= ngw) return ng;
-        uint32_t bits = word_of(any, w) & (0xffffffffu << (from & 31));
-        while (bits == 0) {
-            if (++w >= ngw) return ng;
-            bits = word_of(any, w);
-        }
-        const int g = (w << 5) + __builtin_ctz(bits);
-        return g < ng ? g : ng;
-    };
 
-    // The hi*hi product alone is within rho of the three-term value: a tile in which no row's hi*hi
-    // distance comes within rho of that row's runner-up cannot change anybody's (best, runner-up)
-    // pair, so its two lo products (8 of the 12 MFMAs) are skipped and the lo fragments of the group
-    // are fetched only when some tile asks for them.
+    // needed groups of this wave, compacted: entry = group | (tile bits << 9)
+    int cnt = 0;
+    {
+        const long tile0 = pos0 / 32;
+        for (int base = 0; base < ng; base += 64) {
+            const int g = base + lane;
+            unsigned f = 0;
+            if (g < ng) {
+#pragma unroll
+                for (int b = 0; b < NB; b++)
+                    if (tile0 + b < ntile32) f |= ((mask[(size_t)(tile0 + b) * ngw + (g >> 5)] >> (g & 31)) & 1u) << b;
+            }
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(f != 0);
+            if (f != 0) glist[cnt + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(g | (f << 9));
+            cnt += __builtin_popcountll(bal);
+        }
+    }
+    auto entry = [&](int i) { return __builtin_amdgcn_readfirstlane((int)glist[i]); };
+
     auto load_group = [&](int g, half8 (&ah)[NS], f32x4 (&cn)[4]) {
         const unsigned char* base = img + (size_t)g * GB;
         const half8* fr = reinterpret_cast<const half8*>(base);
 #pragma unroll
-        for (int s = 0; s < NS; s++) ah[s] = fr[(2 * s + 0) * 64 + lane];
-        const float* cnp = reinterpret_cast<const float*>(base + (size_t)32 * D * 4);
+        for (int s = 0; s < NS; s++) ah[s] = fr[s * 64 + lane];
+        const float* cnp = reinterpret_cast<const float*>(base + misc_off(D));
 #pragma unroll
         for (int q = 0; q < 4; q++) cn[q] = *reinterpret_cast<const f32x4*>(cnp + 8 * q + 4 * h);
     };
-    auto compute_group = [&](int g, const half8 (&ah)[NS], const f32x4 (&cnv)[4]) {
-        const uint32_t gbit = 1u << (g & 31);
-        f32x16 acc[NB];
-        bool pass[NB];
-        bool anypass = false;
+    auto screen_min = [&](const f32x16& a, const f32x4 (&cnv)[4]) {
+        float p[16];
 #pragma unroll
-        for (int b = 0; b < NB; b++) {
-            pass[b] = false;
-            if ((word_of(mw[b], g >> 5) & gbit) == 0u) continue;  // wave-uniform
-            f32x16 a = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int r = 0; r < 16; r++) p[r] = __builtin_fmaf(-2.0f, a[r], cnv[r >> 2][r & 3]);
+        return min16(p);
+    };
+    auto refine = [&](int b, int g, f32x16 a, const half8 (&ah)[NS], const half8 (&al)[NS], const f32x4 (&cnv)[4]) {
 #pragma unroll
-            for (int s = 0; s < NS; s++) a = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[b][s], a, 0, 0, 0);
-            float m = __builtin_inff();
-#pragma unroll
-            for (int r = 0; r < 16; r++) m = __builtin_fminf(m, __builtin_fmaf(-2.0f, a[r], cnv[r >> 2][r & 3]));
-            acc[b] = a;
-            pass[b] = __builtin_amdgcn_ballot_w64(m < b2[b] + rho[b]) != 0;
-            anypass |= pass[b];
+        for (int s = 0; s < NS; s++) {
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], xh[b][s], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xl[b][s], a, 0, 0, 0);
         }
-        if (!anypass) return;
-        half8 al[NS];
-        {
-            const half8* fr = reinterpret_cast<const half8*>(img + (size_t)g * GB);
+        float P[16];
 #pragma unroll
-            for (int s = 0; s < NS; s++) al[s] = fr[(2 * s + 1) * 64 + lane];
-        }
-#pragma unroll
-        for (int b = 0; b < NB; b++) {
-            if (!pass[b]) continue;  // wave-uniform
-            f32x16 a = acc[b];
-#pragma unroll
-            for (int s = 0; s < NS; s++) {
-                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], xh[b][s], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xl[b][s], a, 0, 0, 0);
-            }
-            float P[16];
-            float m = __builtin_inff();
+        for (int r = 0; r < 16; r++) P[r] = __builtin_fmaf(-2.0f, a[r], cnv[r >> 2][r & 3]);
+        const float m = min16(P);
+        if (__builtin_amdgcn_ballot_w64(m < b2[b]) != 0) {
+            const float old = b1[b];
+            float v1 = b1[b], v2 = b2[b];
+            unsigned lr = 0;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                P[r] = __builtin_fmaf(-2.0f, a[r], cnv[r >> 2][r & 3]);
-                m = __builtin_fminf(m, P[r]);
+                v2 = __builtin_amdgcn_fmed3f(v1, v2, P[r]);
+                lr = P[r] < v1 ? (unsigned)r : lr;
+                v1 = __builtin_fminf(v1, P[r]);
             }
-            if (__builtin_amdgcn_ballot_w64(m < b2[b]) != 0) {
-                const float old = b1[b];
-                float v1 = b1[b], v2 = b2[b];
-                unsigned lr = 0;
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    v2 = __builtin_amdgcn_fmed3f(v1, v2, P[r]);
-                    lr = P[r] < v1 ? (unsigned)r : lr;
-                    v1 = __builtin_fminf(v1, P[r]);
-                }
-                b1[b] = v1;
-                b2[b] = v2;
-                if (v1 < old) i1[b] = (unsigned)g * 32u + 4u * h + (lr & 3u) + 8u * (lr >> 2);
-            }
+            b1[b] = v1;
+            b2[b] = v2;
+            if (v1 < old) i1[b] = (unsigned)g * 32u + 4u * h + (lr & 3u) + 8u * (lr >> 2);
         }
+    };
+    auto compute_group = [&](int e, const half8 (&ah)[NS], const f32x4 (&cnv)[4]) {
+        const int g = e & 511;
+        const bool need0 = (e >> 9) & 1, need1 = (e >> 10) & 1;  // wave-uniform
+        f32x16 a0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        f32x16 a1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        bool pass0 = false, pass1 = false;
+        if (need0 && need1) {  // the common case: two independent accumulator chains, interleaved
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[0][s], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[1][s], a1, 0, 0, 0);
+            }
+            const float m0 = screen_min(a0, cnv), m1 = screen_min(a1, cnv);
+            pass0 = __builtin_amdgcn_ballot_w64(m0 < b2[0] + rho[0]) != 0;
+            pass1 = __builtin_amdgcn_ballot_w64(m1 < b2[1] + rho[1]) != 0;
+        } else if (need0) {
+#pragma unroll
+            for (int s = 0; s < NS; s++) a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[0][s], a0, 0, 0, 0);
+            pass0 = __builtin_amdgcn_ballot_w64(screen_min(a0, cnv) < b2[0] + rho[0]) != 0;
+        } else {
+#pragma unroll
+            for (int s = 0; s < NS; s++) a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[1][s], a1, 0, 0, 0);
+            pass1 = __builtin_amdgcn_ballot_w64(screen_min(a1, cnv) < b2[1] + rho[1]) != 0;
+        }
+        if (!(pass0 || pass1)) return;
+        half8 al[NS];
+        {
+            const half8* fr = reinterpret_cast<const half8*>(img + (size_t)g * GB + lo_off(D));
+#pragma unroll
+            for (int s = 0; s < NS; s++) al[s] = fr[s * 64 + lane];
+        }
+        if (pass0) refine(0, g, a0, ah, al, cnv);
+        if (pass1) refine(1, g, a1, ah, al, cnv);
     };
 
     half8 ahA[NS], ahB[NS];
     f32x4 cnA[4], cnB[4];
-    int g = next_group(0);
-    if (g < ng) load_group(g, ahA, cnA);
-    while (g < ng) {
-        const int g1 = next_group(g + 1);
-        if (g1 < ng) load_group(g1, ahB, cnB);
-        compute_group(g, ahA, cnA);
-        if (g1 >= ng) break;
-        const int g2 = next_group(g1 + 1);
-        if (g2 < ng) load_group(g2, ahA, cnA);
-        compute_group(g1, ahB, cnB);
-        g = g2;
+    int e0 = 0;
+    if (cnt > 0) {
+        e0 = entry(0);
+        load_group(e0 & 511, ahA, cnA);
+    }
+    for (int i = 0; i < cnt; i += 2) {
+        int e1 = -1;
+        if (i + 1 < cnt) {
+            e1 = entry(i + 1);
+            load_group(e1 & 511, ahB, cnB);
+        }
+        compute_group(e0, ahA, cnA);
+        if (e1 < 0) break;
+        if (i + 2 < cnt) {
+            e0 = entry(i + 2);
+            load_group(e0 & 511, ahA, cnA);
+        }
+        compute_group(e1, ahB, cnB);
     }
 
 #pragma unroll
@@ -291,7 +307,7 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
         const bool unique = ni != NONE && !bad[b] && n1 > -__builtin_inff() && (n2 - n1) > tau[b];
         if (mine) {
             unsigned id = NONE;
-            if (ni != NONE) id = reinterpret_cast<const unsigned*>(img + (size_t)(ni >> 5) * GB + (size_t)32 * D * 4 + 512)[ni & 31];
+            if (ni != NONE) id = reinterpret_cast<const unsigned*>(img + (size_t)(ni >> 5) * GB + misc_off(D) + 128)[ni & 31];
             ids[rowid[b]] = id == NONE ? -1L : (long)id;
             if (approx_out) {  // test hook: approximate distance of the winner and the gap to the runner-up
                 approx_out[2 * rowid[b]] = n1;
