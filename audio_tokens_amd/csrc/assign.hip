@@ -1272,10 +1272,11 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
         // provably out of reach and lists the others; stage 2 below redoes the listed rows with the
         // fp32 sweep.  Coarse mode (guesses only) needs neither the list nor stage 2.
         unsigned* misc = static_cast<unsigned*>(at_ws(ctx, WS_FILTER_MISC, 256, stream));
-        uint32_t* list = static_cast<uint32_t*>(at_ws(ctx, WS_FILTER_LIST, sizeof(uint32_t) * 4 * ((size_t)n + 64), stream));
+        uint32_t* list = static_cast<uint32_t*>(at_ws(ctx, WS_FILTER_LIST, sizeof(uint32_t) * 5 * ((size_t)n + 64), stream));
         if (!misc || !list) return AT_E_NOMEM;
+        uint32_t* aux = list + 4 * ((size_t)n + 64);
         int rc = at_filter_sweep(ctx, x, n, D, c, k, order, cperm, ng, bd, mask, ngw, mode == 0 ? 1 : 0, ids, misc, list,
-                                 nullptr, stream);
+                                 aux, nullptr, stream);
         if (rc) return rc;
         if (dist) {
             rc = mode == 0 ? at_exact_dist_rows(ctx, x, n, D, c, k, ids, dist, order, hint_sorted, bd, stream)
@@ -1297,7 +1298,7 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
         // short lists: one workgroup per row on the vector ALU; long ones (badly conditioned data,
         // centroids outside the fp16 range): the fp32 MFMA sweep over the listed rows
         if ((int64_t)listed * 16 <= n)
-            return at_filter_redo_rows(ctx, x, D, c, k, list, listed, order, cperm, dmin, ng, misc, ids, dist, stream);
+            return at_filter_redo_rows(ctx, x, D, c, k, list, listed, order, cperm, dmin, ng, misc, aux, ids, dist, stream);
         n2 = listed < 64 ? 64 : (int64_t)listed;
         uint32_t* sorted = list + ((size_t)n + 64);
         uint32_t* order_amb = sorted + ((size_t)n + 64);
@@ -1398,11 +1399,12 @@ extern "C" int at_filter_probe_f32(at_ctx* ctx, const float* x, int64_t n, int d
     float* bd = static_cast<float*>(at_ws(ctx, WS_PRUNE_BD, sizeof(float) * (size_t)n, stream));
     uint32_t* mask = static_cast<uint32_t*>(at_ws(ctx, WS_PRUNE_MASK, sizeof(uint32_t) * (size_t)ntile32 * ngw, stream));
     unsigned* misc = static_cast<unsigned*>(at_ws(ctx, WS_FILTER_MISC, 256, stream));
-    uint32_t* list = static_cast<uint32_t*>(at_ws(ctx, WS_FILTER_LIST, sizeof(uint32_t) * 4 * ((size_t)n + 64), stream));
+    uint32_t* list = static_cast<uint32_t*>(at_ws(ctx, WS_FILTER_LIST, sizeof(uint32_t) * 5 * ((size_t)n + 64), stream));
     if (!bd || !mask || !misc || !list) return AT_E_NOMEM;
     int rc = at_prune_prepass(ctx, x, n, d, c, k, order, hint_sorted, dmin, ng, bd, mask, ngw, 0, stream);
     if (rc) return rc;
-    rc = at_filter_sweep(ctx, x, n, d, c, k, order, cperm, ng, bd, mask, ngw, 1, ids, misc, list, approx, stream);
+    rc = at_filter_sweep(ctx, x, n, d, c, k, order, cperm, ng, bd, mask, ngw, 1, ids, misc, list,
+                         list + 4 * ((size_t)n + 64), approx, stream);
     if (rc) return rc;
     unsigned cnt = 0;
     AT_HIP(hipMemcpyAsync(&cnt, misc + 1, sizeof cnt, hipMemcpyDeviceToHost, stream));

@@ -71,7 +71,8 @@ void* at_ws(at_ctx* ctx, int slot, size_t bytes, hipStream_t stream);
 // filter.hip (fp16-split filter of the pruned sweep)
 int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k, const uint32_t* order,
                     const int32_t* cperm, int ng, const float* bd, const uint32_t* mask, int ngw, int collect,
-                    int64_t* ids, unsigned* misc, uint32_t* amb_list, float* approx_out, hipStream_t stream);
+                    int64_t* ids, unsigned* misc, uint32_t* amb_list, uint32_t* amb_aux, float* approx_out,
+                    hipStream_t stream);
 int at_exact_dist_rows(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k, const int64_t* ids,
                        float* dist, const uint32_t* order, const uint32_t* hint_sorted, const float* bd,
                        hipStream_t stream);
@@ -81,6 +82,6 @@ int at_filter_gather_ambiguous(at_ctx* ctx, uint32_t* amb_list, uint32_t* amb_so
 
 int at_filter_redo_rows(at_ctx* ctx, const float* x, int d, const float* c, int k, const uint32_t* list, int64_t m,
                         const uint32_t* order, const int32_t* cperm, const float* dmin, int ng, const unsigned* misc,
-                        int64_t* ids, float* dist, hipStream_t stream);
+                        const uint32_t* aux, int64_t* ids, float* dist, hipStream_t stream);
 
 static inline bool at_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

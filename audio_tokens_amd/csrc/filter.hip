@@ -121,7 +121,8 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
                         const uint32_t* __restrict__ order, const float* __restrict__ bd_in,
                         const uint32_t* __restrict__ mask, int ngw, unsigned* __restrict__ misc, float tau_a,
                         float tau_b, float rho_a, float rho_b, int screen, int collect, long* __restrict__ ids,
-                        uint32_t* __restrict__ amb_list, float* __restrict__ approx_out) {
+                        uint32_t* __restrict__ amb_list, uint32_t* __restrict__ amb_aux,
+                        float* __restrict__ approx_out) {
     static_assert(NB == 2, "written for two 32-row tiles per wave");
     constexpr int NS = D / 16;
     constexpr size_t GB = group_bytes(D);
@@ -136,8 +137,10 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
     const bool c_bad = !(cnmax < RANGE_SQ);
 
     half8 xh[NB][NS], xl[NB][NS];
-    float b1[NB], b2[NB], tau[NB], rho[NB];
-    unsigned i1[NB];
+    // per row (lane-local; the two half-waves hold disjoint centroids of the same row): the three
+    // smallest approximate distances seen and the slots of the two smallest
+    float b1[NB], b2[NB], b3[NB], tau[NB], rho[NB];
+    unsigned i1[NB], i2[NB];
     bool bad[NB];
     long rowid[NB];
 #pragma unroll
@@ -176,8 +179,20 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
         const float cap = bd < __builtin_inff() ? (bd - nrm) + 3.0f * tau[b] : __builtin_inff();
         b1[b] = cap;
         b2[b] = cap;
+        b3[b] = cap;
         i1[b] = NONE;
+        i2[b] = NONE;
     }
+    // insert (P, idx) into a sorted triple (v1 <= v2 <= v3) with the slots of the first two
+    auto insert3 = [](float P, unsigned idx, float& v1, float& v2, float& v3, unsigned& j1, unsigned& j2) {
+        const bool lt1 = P < v1, lt2 = P < v2;
+        const float n3 = __builtin_amdgcn_fmed3f(v2, v3, __builtin_fmaxf(v1, P));
+        j2 = lt1 ? j1 : (lt2 ? idx : j2);
+        v2 = __builtin_amdgcn_fmed3f(v1, v2, P);
+        j1 = lt1 ? idx : j1;
+        v1 = __builtin_fminf(v1, P);
+        v3 = n3;
+    };
 
     // needed groups of this wave, compacted: entry = group | (tile bits << 9)
     int cnt = 0;
@@ -223,19 +238,17 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
 #pragma unroll
         for (int r = 0; r < 16; r++) P[r] = __builtin_fmaf(-2.0f, a[r], cnv[r >> 2][r & 3]);
         const float m = min16(P);
-        if (__builtin_amdgcn_ballot_w64(m < b2[b]) != 0) {
-            const float old = b1[b];
-            float v1 = b1[b], v2 = b2[b];
-            unsigned lr = 0;
+        if (__builtin_amdgcn_ballot_w64(m < b3[b]) != 0) {
+            float v1 = b1[b], v2 = b2[b], v3 = b3[b];
+            unsigned j1 = i1[b], j2 = i2[b];
+            const unsigned base = (unsigned)g * 32u + 4u * h;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                v2 = __builtin_amdgcn_fmed3f(v1, v2, P[r]);
-                lr = P[r] < v1 ? (unsigned)r : lr;
-                v1 = __builtin_fminf(v1, P[r]);
-            }
+            for (int r = 0; r < 16; r++) insert3(P[r], base + (unsigned)((r & 3) + 8 * (r >> 2)), v1, v2, v3, j1, j2);
             b1[b] = v1;
             b2[b] = v2;
-            if (v1 < old) i1[b] = (unsigned)g * 32u + 4u * h + (lr & 3u) + 8u * (lr >> 2);
+            b3[b] = v3;
+            i1[b] = j1;
+            i2[b] = j2;
         }
     };
     auto compute_group = [&](int e, const half8 (&ah)[NS], const f32x4 (&cnv)[4]) {
@@ -251,16 +264,16 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
                 a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[1][s], a1, 0, 0, 0);
             }
             const float m0 = screen_min(a0, cnv), m1 = screen_min(a1, cnv);
-            pass0 = __builtin_amdgcn_ballot_w64(m0 < b2[0] + rho[0]) != 0;
-            pass1 = __builtin_amdgcn_ballot_w64(m1 < b2[1] + rho[1]) != 0;
+            pass0 = __builtin_amdgcn_ballot_w64(m0 < b3[0] + rho[0]) != 0;
+            pass1 = __builtin_amdgcn_ballot_w64(m1 < b3[1] + rho[1]) != 0;
         } else if (need0) {
 #pragma unroll
             for (int s = 0; s < NS; s++) a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[0][s], a0, 0, 0, 0);
-            pass0 = __builtin_amdgcn_ballot_w64(screen_min(a0, cnv) < b2[0] + rho[0]) != 0;
+            pass0 = __builtin_amdgcn_ballot_w64(screen_min(a0, cnv) < b3[0] + rho[0]) != 0;
         } else {
 #pragma unroll
             for (int s = 0; s < NS; s++) a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[1][s], a1, 0, 0, 0);
-            pass1 = __builtin_amdgcn_ballot_w64(screen_min(a1, cnv) < b2[1] + rho[1]) != 0;
+            pass1 = __builtin_amdgcn_ballot_w64(screen_min(a1, cnv) < b3[1] + rho[1]) != 0;
         }
         if (!(pass0 || pass1)) return;
         half8 al[NS];
@@ -295,19 +308,28 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
         compute_group(e1, ahB, cnB);
     }
 
+    auto slot_id = [&](unsigned slot) {
+        return slot == NONE ? NONE
+                            : reinterpret_cast<const unsigned*>(img + (size_t)(slot >> 5) * GB + misc_off(D) + 128)[slot & 31];
+    };
 #pragma unroll
     for (int b = 0; b < NB; b++) {
-        const float o1 = __shfl_xor(b1[b], 32), o2 = __shfl_xor(b2[b], 32);
-        const unsigned oi = (unsigned)__shfl_xor((int)i1[b], 32);
-        const float n1 = __builtin_fminf(b1[b], o1);
-        const float n2 = __builtin_fminf(__builtin_fmaxf(b1[b], o1), __builtin_fminf(b2[b], o2));
-        const unsigned ni = o1 < b1[b] ? oi : i1[b];
+        // merge the other half-wave's triple into this one
+        const float o1 = __shfl_xor(b1[b], 32), o2 = __shfl_xor(b2[b], 32), o3 = __shfl_xor(b3[b], 32);
+        const unsigned oj1 = (unsigned)__shfl_xor((int)i1[b], 32), oj2 = (unsigned)__shfl_xor((int)i2[b], 32);
+        float n1 = b1[b], n2 = b2[b], n3 = b3[b];
+        unsigned nj1 = i1[b], nj2 = i2[b];
+        insert3(o1, oj1, n1, n2, n3, nj1, nj2);
+        insert3(o2, oj2, n1, n2, n3, nj1, nj2);
+        insert3(o3, NONE, n1, n2, n3, nj1, nj2);
         const long pos = pos0 + 32 * b + j;
         const bool mine = h == 0 && pos < n;
-        const bool unique = ni != NONE && !bad[b] && n1 > -__builtin_inff() && (n2 - n1) > tau[b];
+        const bool sane = nj1 != NONE && !bad[b] && n1 > -__builtin_inff();
+        const bool unique = sane && (n2 - n1) > tau[b];
+        // exactly two candidates within reach: the redo only has to score those two
+        const bool pair = sane && nj2 != NONE && (n3 - n1) > tau[b];
         if (mine) {
-            unsigned id = NONE;
-            if (ni != NONE) id = reinterpret_cast<const unsigned*>(img + (size_t)(ni >> 5) * GB + misc_off(D) + 128)[ni & 31];
+            const unsigned id = slot_id(nj1);
             ids[rowid[b]] = id == NONE ? -1L : (long)id;
             if (approx_out) {  // test hook: approximate distance of the winner and the gap to the runner-up
                 approx_out[2 * rowid[b]] = n1;
@@ -323,6 +345,7 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
                 if (mine && !unique) {
                     const unsigned rank = (unsigned)__builtin_popcountll(flagged & ((1ull << lane) - 1ull));
                     amb_list[base + rank] = (uint32_t)pos;
+                    amb_aux[base + rank] = pair ? slot_id(nj2) : NONE;
                 }
             }
         }
@@ -424,7 +447,8 @@ __global__ void __launch_bounds__(WG) exact_rows_kernel(const float* __restrict_
                                                         const uint32_t* __restrict__ order,
                                                         const int32_t* __restrict__ cperm,
                                                         const float* __restrict__ dmin, int ng,
-                                                        const unsigned* __restrict__ misc, long* __restrict__ ids,
+                                                        const unsigned* __restrict__ misc,
+                                                        const uint32_t* __restrict__ aux, long* __restrict__ ids,
                                                         float* __restrict__ dist) {
     __shared__ int needed[512];
     __shared__ int n_needed;
@@ -457,6 +481,16 @@ __global__ void __launch_bounds__(WG) exact_rows_kernel(const float* __restrict_
         }
         return __builtin_fmaxf(__builtin_fmaf(-2.0f, ip, xn + cn), 0.0f);
     };
+    const uint32_t second = aux ? aux[blockIdx.x] : NONE;
+    if (has && second < (uint32_t)k) {  // the filter left exactly two candidates: score both, lowest index on a tie
+        if (tid == 0) {
+            const float d1 = contract_dist(p), d2 = contract_dist((long)second);
+            const bool take2 = d2 < d1 || (d2 == d1 && (long)second < p);
+            ids[row] = take2 ? (long)second : p;
+            if (dist) dist[row] = take2 ? d2 : d1;
+        }
+        return;
+    }
     float tau = __builtin_inff();
     if (has) {
         const float dh = contract_dist(p);
@@ -540,7 +574,8 @@ size_t at_filter_group_bytes(int d) { return group_bytes(d); }
 // amb_list receives their visiting positions (unordered).
 int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k, const uint32_t* order,
                     const int32_t* cperm, int ng, const float* bd, const uint32_t* mask, int ngw, int collect,
-                    int64_t* ids, unsigned* misc, uint32_t* amb_list, float* approx_out, hipStream_t stream) {
+                    int64_t* ids, unsigned* misc, uint32_t* amb_list, uint32_t* amb_aux, float* approx_out,
+                    hipStream_t stream) {
     unsigned char* img = static_cast<unsigned char*>(at_ws(ctx, WS_CENT_IMG16, group_bytes(d) * (size_t)ng, stream));
     if (!img) return AT_E_NOMEM;
     hipLaunchKernelGGL(prep_centroids_f16_kernel, dim3(ng), dim3(WG), 0, stream, c, k, d, cperm, img);
@@ -563,7 +598,8 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
         AT_HIP(hipEventRecord(ctx->filter_ev[0], stream));
     }
     hipLaunchKernelGGL((assign_f16filter_kernel<64, NB>), grid, dim3(64), 0, stream, x, (long)n, img, ng, order, bd,
-                       mask, ngw, misc, ta, tb, ra, rb, screen, collect, reinterpret_cast<long*>(ids), amb_list, approx_out);
+                       mask, ngw, misc, ta, tb, ra, rb, screen, collect, reinterpret_cast<long*>(ids), amb_list, amb_aux,
+                       approx_out);
     AT_LAUNCH_CHECK();
     if (collect) AT_HIP(hipEventRecord(ctx->filter_ev[1], stream));
     return AT_OK;
@@ -614,16 +650,16 @@ int at_filter_gather_ambiguous(at_ctx* ctx, uint32_t* amb_list, uint32_t* amb_so
 // Stage 2 for short lists: one workgroup per listed row (see exact_rows_kernel).
 int at_filter_redo_rows(at_ctx* ctx, const float* x, int d, const float* c, int k, const uint32_t* list, int64_t m,
                         const uint32_t* order, const int32_t* cperm, const float* dmin, int ng, const unsigned* misc,
-                        int64_t* ids, float* dist, hipStream_t stream) {
+                        const uint32_t* aux, int64_t* ids, float* dist, hipStream_t stream) {
     (void)ctx;
     if (m <= 0) return AT_OK;
     AT_REQUIRE(ng <= 512, "at_filter_redo_rows: ng > 512");
     if (d == 64)
         hipLaunchKernelGGL(exact_rows_kernel<64>, dim3((unsigned)m), dim3(WG), 0, stream, x, c, k, list, order, cperm, dmin,
-                           ng, misc, reinterpret_cast<long*>(ids), dist);
+                           ng, misc, aux, reinterpret_cast<long*>(ids), dist);
     else
         hipLaunchKernelGGL(exact_rows_kernel<128>, dim3((unsigned)m), dim3(WG), 0, stream, x, c, k, list, order, cperm,
-                           dmin, ng, misc, reinterpret_cast<long*>(ids), dist);
+                           dmin, ng, misc, aux, reinterpret_cast<long*>(ids), dist);
     AT_LAUNCH_CHECK();
     return AT_OK;
 }

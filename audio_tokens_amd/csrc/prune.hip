@@ -150,24 +150,51 @@ __global__ void __launch_bounds__(WG) prune_mask_kernel(const float* __restrict_
     const float tau = !live ? -1.0f
                             : (has ? 2.0f * sqrtf(dh + delta) * (1.0f + 4.0f * U32) + 1e-30f : __builtin_inff());
 
-    const float* drow = dmin + (size_t)(has ? p : 0) * ng;
+    // Rows arrive sorted by guess, so a 32-row tile holds a few runs of equal p: a group is needed by
+    // the tile iff dmin[p][g] <= the largest tau of some run.  Lanes stand for groups here (64 per
+    // pass, one coalesced read of the run's dmin row), not for rows.
     const long tile = wpos / 32;
     const bool second = wpos + 32 < n;
     int needed = 0;
-    for (int w = 0; w < ngw; w++) {
-        uint32_t bitsA = 0, bitsB = 0;
-        const int g1 = min(32, ng - 32 * w);
-        for (int gg = 0; gg < g1; gg++) {
-            const bool need = drow[32 * w + gg] <= tau;     // +inf tau: always; dead lane: never
-            const unsigned long long b = __builtin_amdgcn_ballot_w64(need);
-            bitsA |= (uint32_t)((b & 0xffffffffull) != 0) << gg;
-            bitsB |= (uint32_t)((b >> 32) != 0) << gg;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        if (half == 1 && !second) break;
+        const unsigned long long hm = half ? 0xffffffff00000000ull : 0x00000000ffffffffull;
+        const bool mine = live && ((lane >> 5) == half);
+        const bool all = (__builtin_amdgcn_ballot_w64(mine && !has) != 0);
+        unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (all) {
+#pragma unroll
+            for (int it = 0; it < 8; it++) acc[it] = ~0ull;
+        } else {
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(mine) & hm;
+            while (todo != 0) {
+                const int leader = __builtin_ctzll(todo);
+                const uint32_t pl = (uint32_t)__builtin_amdgcn_readlane((int)p, leader);
+                const bool in_run = mine && p == pl;
+                todo &= ~__builtin_amdgcn_ballot_w64(in_run);
+                float t = in_run ? tau : -1.0f;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) t = __builtin_fmaxf(t, __shfl_xor(t, off));
+                const float* drow = dmin + (size_t)pl * ng;
+#pragma unroll
+                for (int it = 0; it < 8; it++) {
+                    const int g = 64 * it + lane;
+                    if (64 * it < ng) acc[it] |= __builtin_amdgcn_ballot_w64(g < ng && drow[g] <= t);
+                }
+            }
         }
-        if (lane == 0) {
-            mask[(size_t)tile * ngw + w] = bitsA;
-            if (second) mask[(size_t)(tile + 1) * ngw + w] = bitsB;
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            if (64 * it >= ng) break;
+            unsigned long long v = acc[it];
+            if (ng - 64 * it < 64) v &= (1ull << (ng - 64 * it)) - 1ull;
+            if (lane == 0) {
+                mask[(size_t)(tile + half) * ngw + 2 * it] = (uint32_t)v;
+                if (2 * it + 1 < ngw) mask[(size_t)(tile + half) * ngw + 2 * it + 1] = (uint32_t)(v >> 32);
+            }
+            needed += __builtin_popcountll(v);
         }
-        needed += __builtin_popcount(bitsA) + (second ? __builtin_popcount(bitsB) : 0);
     }
     if (lane == 0) {  // statistics only (256 slots to keep the atomics off one address)
         unsigned long long* slot = stats + 2 * (blockIdx.x & 255);
