@@ -292,6 +292,24 @@ class HipBackend(HostHelpers):
         np.bitwise_or.at(bits, (rows, (nb >> 5).ravel()), (np.uint32(1) << (nb & 31).astype(np.uint32)).ravel())
         return self.from_host(bits.view(np.int32))
 
+    def _nearest_mean(self, x, means):
+        """Group of the (approximately) nearest group mean -- a guess, so at d = 64 it is taken from the
+        fp16 filter sweep over all groups of means instead of the dense fp32 sweep."""
+        n, d = x.shape
+        ngm = means.shape[0]
+        if d != 64 or n < 20 or os.environ.get("AT_FILTER", "1") == "0":
+            return self.assign(x, means, want_dist=False)[0]
+        key = (n, ngm)
+        if getattr(self, "_ident", (None,))[0] != key:
+            g8 = (ngm + 31) // 32
+            perm = torch.full((g8 * 32,), -1, dtype=torch.int32, device=self.device)
+            perm[:ngm] = torch.arange(ngm, dtype=torch.int32, device=self.device)
+            every = torch.full((g8, (g8 + 31) // 32), -1, dtype=torch.int32, device=self.device)   # all bits set
+            self._ident = (key, torch.arange(n, dtype=torch.int32, device=self.device),
+                           torch.zeros(n, dtype=torch.int32, device=self.device), perm, every)
+        _, order, zeros, perm, every = self._ident
+        return self.assign_pruned(x, means, (order, zeros), perm, every, want_dist=False, mode=1, filter=True)[0]
+
     def assign_c2f(self, x, c, cperm, dmin, gnbr=None, want_dist=True):
         """Exact nearest centroid without guesses: nearest group mean -> best member of that group
         and its neighbour groups (a guess) -> pruned exact sweep.  Same result as assign()."""
@@ -300,7 +318,7 @@ class HipBackend(HostHelpers):
         means = self.group_means(c, cperm)
         if gnbr is None:
             gnbr = self.group_neighbours(means)
-        gx, _ = self.assign(x, means, want_dist=False)
+        gx = self._nearest_mean(x, means)
         guess, gdis = self.assign_pruned(x, c, self.visit_order(gx, None, ng), cperm, gnbr, mode=1)
         return self.assign_pruned(x, c, self.visit_order(guess, gdis, c.shape[0]), cperm, dmin, want_dist=want_dist)
 
@@ -318,7 +336,7 @@ class HipBackend(HostHelpers):
         order, hint_sorted = order
         ng = cperm.numel() // 32
         ids = self.empty((n,), torch.int64)
-        dist = self.empty((n,), torch.float32) if (want_dist or mode == 1) else None
+        dist = self.empty((n,), torch.float32) if want_dist else None
         rec = self.assign_trace
         with torch.cuda.device(self.device):
             # pre-pass (bound + masks) first, so that the events below bracket the sweep kernel only

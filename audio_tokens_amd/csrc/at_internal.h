@@ -41,6 +41,8 @@ struct at_ctx {
     hipEvent_t filter_ev[2];             // around the stage-1 kernel of exact calls (created on first use)
     double filter_ms;                    // summed stage-1 kernel time, over filter_launches launches
     int64_t filter_launches;
+    hipStream_t side_stream;             // centroid_accum: long member lists beside the short ones
+    hipEvent_t side_ev[2];
 };
 
 int at_fail(int code, const char* fmt, ...);

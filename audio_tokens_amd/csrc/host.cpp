@@ -61,8 +61,11 @@ void at_destroy(at_ctx* ctx) {
     (void)hipDeviceSynchronize();
     for (int i = 0; i < WS_NSLOTS; i++)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 2; i++) {
         if (ctx->filter_ev[i]) (void)hipEventDestroy(ctx->filter_ev[i]);
+        if (ctx->side_ev[i]) (void)hipEventDestroy(ctx->side_ev[i]);
+    }
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     (void)hipSetDevice(prev);
     delete ctx;
 }

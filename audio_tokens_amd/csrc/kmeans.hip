@@ -348,6 +348,24 @@ int at_centroid_accum_f32(at_ctx* ctx, const float* x, int64_t n, int d, const i
     // member lists longer than this go to the feature-sliced workgroup kernel
     const bool long_ok = d % 4 == 0 && al;
     const uint32_t long_list = long_ok ? 2048u : UINT32_MAX;
+    // The long lists are one dependent add chain per feature (the contract's summation order), a few
+    // workgroups busy for as long as the longest list takes: they run on a side stream beside the
+    // kernel that handles all the other clusters.
+    const bool have_long = long_ok && n > (int64_t)long_list;
+    if (have_long) {
+        if (!ctx->side_stream) {
+            AT_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+            AT_HIP(hipEventCreateWithFlags(&ctx->side_ev[0], hipEventDisableTiming));
+            AT_HIP(hipEventCreateWithFlags(&ctx->side_ev[1], hipEventDisableTiming));
+        }
+        AT_HIP(hipEventRecord(ctx->side_ev[0], stream));
+        AT_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->side_ev[0], 0));
+        // (workgroups of short clusters exit at once; gridDim.y = feature slices)
+        hipLaunchKernelGGL(centroid_accum_long_kernel, dim3(k, d / 4), dim3(WG), 0, ctx->side_stream, x, d, order,
+                           offsets, long_list, sums, counts);
+        AT_LAUNCH_CHECK();
+        AT_HIP(hipEventRecord(ctx->side_ev[1], ctx->side_stream));
+    }
     if (vec == 4)
         hipLaunchKernelGGL(centroid_accum_kernel<4>, grid, dim3(WG), 0, stream, x, d, order, offsets, k,
                            slabs, long_list, sums, counts);
@@ -363,11 +381,7 @@ int at_centroid_accum_f32(at_ctx* ctx, const float* x, int64_t n, int d, const i
     if (sorted_ids_out && n > 0)
         AT_HIP(hipMemcpyAsync(sorted_ids_out, sorted_keys, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice,
                               stream));
-    if (long_ok && n > (int64_t)long_list) {
-        // (workgroups of short clusters exit at once; gridDim.y = feature slices)
-        hipLaunchKernelGGL(centroid_accum_long_kernel, dim3(k, d / 4), dim3(WG), 0, stream, x, d, order,
-                           offsets, long_list, sums, counts);
-    }
+    if (have_long) AT_HIP(hipStreamWaitEvent(stream, ctx->side_ev[1], 0));
     AT_LAUNCH_CHECK();
     return AT_OK;
 }
