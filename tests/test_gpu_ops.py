@@ -132,7 +132,7 @@ def test_assign_pruned_is_exact(be, oracle, monkeypatch, n, d, k, lds_kernel):
 def _filter_eps(d, H):
     """The a-priori bound of csrc/filter.hip on |P16 + |x|^2 - true squared distance| (header there)."""
     u, q, m = 2.0 ** -24, np.sqrt(d) * 2.0 ** -25, 3.0 * d / 16.0
-    return H * (17 * m * u * 1.01 + 3 * 2.0 ** -23 + d * u * 1.01 + 2 * u + 2 * q) + 4 * q
+    return H * (34 * m * u * 1.01 + 3 * 2.0 ** -22 + d * u * 1.01 + 2 * u + 2 * q) + 4 * q
 
 
 @pytest.mark.parametrize("scale_x,scale_c", [(1.0, 1.0), (30.0, 0.02), (0.003, 7.0), (1000.0, 1000.0)])
