@@ -34,7 +34,7 @@ struct at_ctx {
     void* ws[WS_NSLOTS];
     size_t ws_bytes[WS_NSLOTS];
     // cached description of what WS_LOGMEL_FB currently holds
-    int fb_sr, fb_nfft, fb_nmels, fb_nw;
+    int fb_sr, fb_nfft, fb_nmels, fb_nw, fb_hop, fb_quads;
     const float* fb_user;
     int rs_orig, rs_new;  // what WS_RESAMPLE_TAPS currently holds
     int64_t filter_rows, filter_listed;  // fp16-split filter: rows swept / rows handed to the fp32 redo

@@ -41,6 +41,7 @@ struct LogmelParams {
     const float* fb_wts;    // concatenated non-zero bands
     int fb_nw;              // number of weights; tables are copied to LDS when fb_lds != 0
     int fb_lds;
+    int fb_quads;           // bands padded to 4-aligned quads of bins (16-byte reads) or stored as they are
     float* out;
     int frame_major, fuse_l2norm;
 };
@@ -56,17 +57,20 @@ __global__ void __launch_bounds__(WG, 2) logmel_kernel(LogmelParams p) {
     float* samp = tabs + TAB_FLOATS;               // nsamp (rounded up to 4)
     float* work = samp + ((nsamp + 3) & ~3);       // 16 frames x FRAME_LDS_FLOATS
     float* ostage = work + 16 * FRAME_LDS_FLOATS;  // fpb x opitch  (+ fpb denominators)
-    int* fbi = reinterpret_cast<int*>(ostage + p.fpb * opitch + p.fpb);  // start | len | off | weights
+    // filterbank tables behind the staging area, 16-byte aligned: start4 | quads | off | padded weights
+    int* fbi = reinterpret_cast<int*>(sm + ((TAB_FLOATS + ((nsamp + 3) & ~3) + 16 * FRAME_LDS_FLOATS +
+                                             p.fpb * opitch + p.fpb + 3) & ~3));
     const int* fb_start = p.fb_start;
     const int* fb_len = p.fb_len;
     const int* fb_off = p.fb_off;
     const float* fb_wts = p.fb_wts;
     if (p.fb_lds) {
-        for (int i = tid; i < 3 * p.n_mels + p.fb_nw; i += WG) fbi[i] = p.fb_start[i];  // one contiguous blob
+        const int nint = (3 * p.n_mels + 3) & ~3;
+        for (int i = tid; i < nint + p.fb_nw; i += WG) fbi[i] = p.fb_start[i];  // one contiguous blob
         fb_start = fbi;
         fb_len = fbi + p.n_mels;
         fb_off = fbi + 2 * p.n_mels;
-        fb_wts = reinterpret_cast<const float*>(fbi + 3 * p.n_mels);
+        fb_wts = reinterpret_cast<const float*>(fbi + nint);
     }
 
     const long clip = blockIdx.y;
@@ -101,11 +105,12 @@ __global__ void __launch_bounds__(WG, 2) logmel_kernel(LogmelParams p) {
         phase3_power(l16, z, mybuf, tabs + TAB_TW512, pw, p256);
 #pragma unroll
         for (int e = 0; e < 16; e++) mybuf[l16 + 16 * e] = pw[e];
-        if (l16 == 0) mybuf[256] = p256;
+        if (l16 < 4) mybuf[256 + l16] = l16 == 0 ? p256 : 0.0f;  // bins 257..259 pad the last quad
         for (int i = 0; i < n_mel_iter; i++) {
             const int m = l16 + 16 * i;
             if (m < p.n_mels) {
-                float s = mel_band(mybuf, fb_start[m], fb_len[m], fb_wts + fb_off[m]);
+                const float s = p.fb_quads ? mel_band(mybuf, fb_start[m], fb_len[m], fb_wts + fb_off[m])
+                                           : mel_band_plain(mybuf, fb_start[m], fb_len[m], fb_wts + fb_off[m]);
                 // clamp(x, 1e-10) then 10*log10: a clamped bin is exactly -100 dB (what a correctly
                 // rounded log10 of 1e-10f gives; the device log10f is 1 ulp off there)
                 ostage[f * opitch + m] = s > 1e-10f ? 10.0f * log10f(s) : -100.0f;
@@ -140,11 +145,19 @@ __global__ void __launch_bounds__(WG, 2) logmel_kernel(LogmelParams p) {
 }
 
 // Host side: window / twiddles / banded filterbank, uploaded once per (sr, n_mels, fb) change.
-int build_tables(at_ctx* ctx, int sample_rate, int n_mels, const float* fb_user_dev, hipStream_t stream,
+// LDS bytes of one workgroup of `fpb` frames (kernel layout), with `fb_ints` words of filterbank tables
+size_t lds_bytes(int fpb, int hop, int n_mels, size_t fb_ints) {
+    const int nsamp = (fpb - 1) * hop + NFFT;
+    return sizeof(float) * ((size_t)TAB_FLOATS + ((nsamp + 3) & ~3) + 16 * FRAME_LDS_FLOATS + (size_t)fpb * (n_mels + 1) + fpb) +
+           fb_ints * 4 + 16;
+}
+constexpr size_t LDS_TWO_PER_CU = 80 * 1024;  // two workgroups of this size share a CU
+
+int build_tables(at_ctx* ctx, int sample_rate, int n_mels, int hop, const float* fb_user_dev, hipStream_t stream,
                  const float** tabs, const int** st, const int** ln, const int** of, const float** wt,
-                 int* n_weights) {
+                 int* n_weights, int* quads) {
     const bool cached = ctx->ws[WS_LOGMEL_FB] && ctx->fb_sr == sample_rate && ctx->fb_nfft == NFFT &&
-                        ctx->fb_nmels == n_mels && ctx->fb_user == fb_user_dev;
+                        ctx->fb_nmels == n_mels && ctx->fb_user == fb_user_dev && ctx->fb_hop == hop;
     std::vector<float> fb((size_t)NBIN * n_mels);
     std::vector<int> start(n_mels), len(n_mels), off(n_mels);
     std::vector<float> wts;
@@ -158,19 +171,32 @@ int build_tables(at_ctx* ctx, int sample_rate, int n_mels, const float* fb_user_
             int rc = at_mel_filterbank_host(sample_rate, NFFT, n_mels, fb.data());
             if (rc) return rc;
         }
-        for (int m = 0; m < n_mels; m++) {
-            int lo = NBIN, hi = -1;
-            for (int f = 0; f < NBIN; f++)
-                if (fb[(size_t)f * n_mels + m] != 0.0f) { lo = f < lo ? f : lo; hi = f; }
-            start[m] = hi < 0 ? 0 : lo;
-            len[m] = hi < 0 ? 0 : hi - lo + 1;
-            off[m] = (int)wts.size();
-            for (int f = start[m]; f < start[m] + len[m]; f++) wts.push_back(fb[(size_t)f * n_mels + m]);
+        // Bands padded with zero weights to whole 4-aligned quads of bins (16-byte LDS reads, see
+        // logmel_core.h mel_band) -- unless the padding is what pushes a 32-frame workgroup past half
+        // a CU's LDS, in which case the bands are stored as they are.
+        const size_t nint0 = ((size_t)3 * n_mels + 3) & ~(size_t)3;
+        for (int gran = 4; gran >= 1; gran -= 3) {
+            wts.clear();
+            for (int m = 0; m < n_mels; m++) {
+                int lo = NBIN, hi = -1;
+                for (int f = 0; f < NBIN; f++)
+                    if (fb[(size_t)f * n_mels + m] != 0.0f) { lo = f < lo ? f : lo; hi = f; }
+                const int s4 = hi < 0 ? 0 : (lo / gran) * gran;
+                const int e4 = hi < 0 ? 0 : ((hi + gran) / gran) * gran;
+                start[m] = s4;
+                len[m] = (e4 - s4) / gran;
+                off[m] = (int)wts.size();
+                for (int f = s4; f < e4; f++) wts.push_back(f < NBIN ? fb[(size_t)f * n_mels + m] : 0.0f);
+            }
+            ctx->fb_quads = gran == 4;
+            const bool fits = lds_bytes(32, hop, n_mels, nint0 + wts.size()) <= LDS_TWO_PER_CU;
+            const bool lds_ok = (nint0 + wts.size()) * 4 <= 14 * 1024;
+            if (gran == 1 || fits || !lds_ok) break;  // (a dense user filterbank stays in global memory: quads)
         }
     }
-    // layout: [tabs TAB_FLOATS f32][start n_mels i32][len][off][wts ...]; worst case all bins per filter
-    const size_t cap = sizeof(float) * TAB_FLOATS + sizeof(int) * 3 * (size_t)n_mels +
-                       sizeof(float) * (size_t)NBIN * n_mels;
+    // layout: [tabs TAB_FLOATS f32][start4 n_mels i32][quads][off][pad to 4 ints][wts ...]; worst case all bins
+    const size_t nint = ((size_t)3 * n_mels + 3) & ~(size_t)3;
+    const size_t cap = sizeof(float) * TAB_FLOATS + sizeof(int) * nint + sizeof(float) * (size_t)(NBIN + 3) * n_mels;
     if (!cached) {
         base = static_cast<char*>(at_ws(ctx, WS_LOGMEL_FB, cap, stream));
         if (!base) return AT_E_NOMEM;
@@ -183,27 +209,29 @@ int build_tables(at_ctx* ctx, int sample_rate, int n_mels, const float* fb_user_
             t[TAB_TW512 + 2 * j] = (float)std::cos(2.0 * M_PI * j / 512.0);
             t[TAB_TW512 + 2 * j + 1] = (float)-std::sin(2.0 * M_PI * j / 512.0);
         }
-        std::vector<char> blob(sizeof(float) * TAB_FLOATS + sizeof(int) * 3 * (size_t)n_mels +
-                               sizeof(float) * wts.size());
+        std::vector<char> blob(sizeof(float) * TAB_FLOATS + sizeof(int) * nint + sizeof(float) * wts.size(), 0);
         char* q = blob.data();
         std::memcpy(q, t.data(), sizeof(float) * TAB_FLOATS); q += sizeof(float) * TAB_FLOATS;
         std::memcpy(q, start.data(), sizeof(int) * n_mels); q += sizeof(int) * n_mels;
         std::memcpy(q, len.data(), sizeof(int) * n_mels); q += sizeof(int) * n_mels;
         std::memcpy(q, off.data(), sizeof(int) * n_mels); q += sizeof(int) * n_mels;
+        q = blob.data() + sizeof(float) * TAB_FLOATS + sizeof(int) * nint;
         if (!wts.empty()) std::memcpy(q, wts.data(), sizeof(float) * wts.size());
         bytes = blob.size();
         AT_HIP(hipStreamSynchronize(stream));
         AT_HIP(hipMemcpy(base, blob.data(), bytes, hipMemcpyHostToDevice));
         ctx->fb_sr = sample_rate; ctx->fb_nfft = NFFT; ctx->fb_nmels = n_mels; ctx->fb_user = fb_user_dev;
         ctx->fb_nw = (int)wts.size();
+        ctx->fb_hop = hop;
     } else {
         base = static_cast<char*>(ctx->ws[WS_LOGMEL_FB]);
     }
     *tabs = reinterpret_cast<const float*>(base);
     const int* ints = reinterpret_cast<const int*>(base + sizeof(float) * TAB_FLOATS);
     *st = ints; *ln = ints + n_mels; *of = ints + 2 * n_mels;
-    *wt = reinterpret_cast<const float*>(ints + 3 * n_mels);
+    *wt = reinterpret_cast<const float*>(ints + nint);
     *n_weights = ctx->fb_nw;
+    *quads = ctx->fb_quads;
     return AT_OK;
 }
 
@@ -228,22 +256,24 @@ extern "C" int at_logmel_f32(at_ctx* ctx, const float* wave, int64_t n_clips, in
     AT_HIP(hipSetDevice(ctx->device));
 
     LogmelParams p;
-    int rc = build_tables(ctx, sample_rate, n_mels, fb_or_null, stream, &p.tabs, &p.fb_start, &p.fb_len,
-                          &p.fb_off, &p.fb_wts, &p.fb_nw);
+    int rc = build_tables(ctx, sample_rate, n_mels, hop, fb_or_null, stream, &p.tabs, &p.fb_start, &p.fb_len,
+                          &p.fb_off, &p.fb_wts, &p.fb_nw, &p.fb_quads);
     if (rc) return rc;
     const int64_t T = at_num_frames(L, hop);
     AT_REQUIRE(T < (1LL << 31), "at_logmel_f32: too many frames per clip");
     p.wave = wave; p.n_clips = n_clips; p.L = L; p.wave_stride = wave_stride;
     p.hop = hop; p.T = (int)T; p.n_mels = n_mels;
-    p.fpb = (31 * hop + NFFT) * 4 <= 20 * 1024 ? 32 : 16;
     p.out = out; p.frame_major = layout == AT_LAYOUT_FRAME_MAJOR; p.fuse_l2norm = fuse_l2norm;
-
-    const int nsamp = (p.fpb - 1) * hop + NFFT;
-    size_t lds = sizeof(float) * ((size_t)TAB_FLOATS + ((nsamp + 3) & ~3) + 16 * FRAME_LDS_FLOATS +
-                                  (size_t)p.fpb * (n_mels + 1) + p.fpb);
     // the banded filterbank rides in LDS too unless a dense user filterbank makes it too big
-    p.fb_lds = (3 * (size_t)n_mels + p.fb_nw) * 4 <= 12 * 1024;
-    if (p.fb_lds) lds += (3 * (size_t)n_mels + p.fb_nw) * 4;
+    const size_t fb_ints = (((size_t)3 * n_mels + 3) & ~(size_t)3) + p.fb_nw;
+    p.fb_lds = fb_ints * 4 <= 14 * 1024;
+    // 32 frames per workgroup when two workgroups of that size still share a CU's 160 KiB of LDS
+    // (the kernel is latency-bound: one workgroup per CU runs at half the rate), else 16
+    size_t lds = 0;
+    for (p.fpb = 32; p.fpb >= 16; p.fpb -= 16) {
+        lds = lds_bytes(p.fpb, hop, n_mels, p.fb_lds ? fb_ints : 0);
+        if (lds <= LDS_TWO_PER_CU || p.fpb == 16) break;
+    }
     AT_REQUIRE(lds <= 160 * 1024, "at_logmel_f32: n_mels=%d needs %zu bytes of LDS", n_mels, lds);
     static size_t attr_lds = 0;
     if (lds > attr_lds) {

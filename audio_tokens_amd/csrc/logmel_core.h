@@ -140,8 +140,27 @@ AT_HD void phase3_power(int l, const cpx (&z)[16], const float* zbuf, const floa
     }
 }
 
-// Phase 4: one mel filter = banded dot product over the power spectrum, then dB.
-AT_HD float mel_band(const float* pw, int start, int len, const float* wts) {
+// Phase 4: one mel filter = banded dot product over the power spectrum.  The band is stored padded
+// with zero weights to whole, 4-aligned quads of bins (start4 % 4 == 0, n4 quads), so the device
+// reads power and weights 16 bytes at a time; a zero weight leaves the running sum unchanged.
+AT_HD float mel_band(const float* pw, int start4, int n4, const float* wts) {
+    float s = 0.0f;
+    for (int q = 0; q < n4; q++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 pv = *reinterpret_cast<const f4*>(pw + start4 + 4 * q);
+        const f4 wv = *reinterpret_cast<const f4*>(wts + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; e++) s = __builtin_fmaf(pv[e], wv[e], s);
+#else
+        for (int e = 0; e < 4; e++) s = __builtin_fmaf(pw[start4 + 4 * q + e], wts[4 * q + e], s);
+#endif
+    }
+    return s;
+}
+
+// The same with the band stored as it is (start, length in bins): 4-byte reads.
+AT_HD float mel_band_plain(const float* pw, int start, int len, const float* wts) {
     float s = 0.0f;
     for (int w = 0; w < len; w++) s = __builtin_fmaf(pw[start + w], wts[w], s);
     return s;
