@@ -370,15 +370,19 @@ __global__ void __launch_bounds__(WG) exact_dist_rows_kernel(const float* __rest
     }
     const f32x4* px = reinterpret_cast<const f32x4*>(X + i * D);
     const f32x4* pc = reinterpret_cast<const f32x4*>(C + p * D);
+    f32x4 xv[D / 4], cv[D / 4];  // all loads in flight before the first dependent fma
+#pragma unroll
+    for (int q = 0; q < D / 4; q++) xv[q] = px[q];
+#pragma unroll
+    for (int q = 0; q < D / 4; q++) cv[q] = pc[q];
     float xn = 0.0f, cn = 0.0f, ip = 0.0f;
-#pragma clang loop unroll(disable)
+#pragma unroll
     for (int q = 0; q < D / 4; q++) {
-        const f32x4 u = px[q], cu = pc[q];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            xn = __builtin_fmaf(u[e], u[e], xn);
-            cn = __builtin_fmaf(cu[e], cu[e], cn);
-            ip = __builtin_fmaf(cu[e], u[e], ip);
+            xn = __builtin_fmaf(xv[q][e], xv[q][e], xn);
+            cn = __builtin_fmaf(cv[q][e], cv[q][e], cn);
+            ip = __builtin_fmaf(cv[q][e], xv[q][e], ip);
         }
     }
     dist[i] = __builtin_fmaxf(__builtin_fmaf(-2.0f, ip, xn + cn), 0.0f);
@@ -408,15 +412,19 @@ __global__ void __launch_bounds__(WG) exact_dist_visit_kernel(const float* __res
     }
     const f32x4* px = reinterpret_cast<const f32x4*>(X + i * D);
     const f32x4* pc = reinterpret_cast<const f32x4*>(C + p * D);
+    f32x4 xv[D / 4], cv[D / 4];  // all loads in flight before the first dependent fma
+#pragma unroll
+    for (int q = 0; q < D / 4; q++) xv[q] = px[q];
+#pragma unroll
+    for (int q = 0; q < D / 4; q++) cv[q] = pc[q];
     float xn = 0.0f, cn = 0.0f, ip = 0.0f;
-#pragma clang loop unroll(disable)
+#pragma unroll
     for (int q = 0; q < D / 4; q++) {
-        const f32x4 u = px[q], cu = pc[q];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            xn = __builtin_fmaf(u[e], u[e], xn);
-            cn = __builtin_fmaf(cu[e], cu[e], cn);
-            ip = __builtin_fmaf(cu[e], u[e], ip);
+            xn = __builtin_fmaf(xv[q][e], xv[q][e], xn);
+            cn = __builtin_fmaf(cv[q][e], cv[q][e], cn);
+            ip = __builtin_fmaf(cv[q][e], xv[q][e], ip);
         }
     }
     dist[i] = __builtin_fmaxf(__builtin_fmaf(-2.0f, ip, xn + cn), 0.0f);

@@ -129,15 +129,22 @@ __global__ void __launch_bounds__(WG) prune_mask_kernel(const float* __restrict_
     const bool has = p < (uint32_t)k;
     const f32x4_t* px = reinterpret_cast<const f32x4_t*>(X + r * D);
     const f32x4_t* pc = reinterpret_cast<const f32x4_t*>(C + (size_t)(has ? p : 0) * D);
+    // every load of the two rows is issued before the first dependent fma: a row-per-lane read that
+    // waits for each 16-byte piece in turn keeps its 128-byte lines alive for many microseconds, and
+    // with 2048 waves doing so they fall out of L2 and are fetched again (2.4x the bytes, measured)
+    f32x4_t xv[D / 4], cv[D / 4];
+#pragma unroll
+    for (int q = 0; q < D / 4; q++) xv[q] = px[q];
+#pragma unroll
+    for (int q = 0; q < D / 4; q++) cv[q] = pc[q];
     float xn = 0.0f, cn = 0.0f, ip = 0.0f;
-#pragma clang loop unroll(disable)
+#pragma unroll
     for (int q = 0; q < D / 4; q++) {
-        const f32x4_t u = px[q], cu = pc[q];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            xn = __builtin_fmaf(u[e], u[e], xn);
-            cn = __builtin_fmaf(cu[e], cu[e], cn);
-            ip = __builtin_fmaf(cu[e], u[e], ip);
+            xn = __builtin_fmaf(xv[q][e], xv[q][e], xn);
+            cn = __builtin_fmaf(cv[q][e], cv[q][e], cn);
+            ip = __builtin_fmaf(cv[q][e], xv[q][e], ip);
         }
     }
     // exactly the value the MFMA sweep would produce for (x, c_p)
