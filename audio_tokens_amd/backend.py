@@ -356,12 +356,15 @@ class HipBackend(HostHelpers):
 
     def filter_stats(self, reset=True, timing=False):
         """(rows swept by the fp16-split filter, rows it handed to the fp32 sweep) since the last reset;
-        with timing also (summed HIP-event ms of the stage-1 kernel, number of exact sweeps timed)."""
+        with timing also (summed HIP-event ms of the stage-1 kernel, number of exact sweeps timed,
+        32x32 tiles multiplied hi*hi, tiles refined with the lo products)."""
         a, b = ctypes.c_int64(0), ctypes.c_int64(0)
         ms, cnt = ctypes.c_double(0.0), ctypes.c_int64(0)
+        tiles, refined = ctypes.c_int64(0), ctypes.c_int64(0)
         _lib.check(self.lib.at_filter_stats(self.ctx.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(ms),
-                                            ctypes.byref(cnt), 1 if reset else 0))
-        return (a.value, b.value, ms.value, cnt.value) if timing else (a.value, b.value)
+                                            ctypes.byref(cnt), ctypes.byref(tiles), ctypes.byref(refined),
+                                            1 if reset else 0))
+        return (a.value, b.value, ms.value, cnt.value, tiles.value, refined.value) if timing else (a.value, b.value)
 
     def filter_probe(self, x, c, order, cperm, dmin):
         """Test hook: stage 1 only -> (winner ids, approx [n, 2] = (P of the winner, gap to runner-up), listed)."""

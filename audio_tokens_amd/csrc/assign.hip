@@ -1284,11 +1284,16 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
             if (rc) return rc;
         }
         if (mode != 0) return AT_OK;
-        unsigned listed = 0;
-        AT_HIP(hipMemcpyAsync(&listed, misc + 1, sizeof listed, hipMemcpyDeviceToHost, stream));
+        unsigned host_misc[64];
+        AT_HIP(hipMemcpyAsync(host_misc, misc, sizeof host_misc, hipMemcpyDeviceToHost, stream));
         AT_HIP(hipStreamSynchronize(stream));
+        const unsigned listed = host_misc[1];
         ctx->filter_rows += n;
         ctx->filter_listed += listed;
+        for (int i = 0; i < 16; i++) {
+            ctx->filter_tiles += host_misc[4 + 2 * i];
+            ctx->filter_refined += host_misc[5 + 2 * i];
+        }
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, ctx->filter_ev[0], ctx->filter_ev[1]) == hipSuccess) {
             ctx->filter_ms += ms;
@@ -1369,14 +1374,16 @@ extern "C" int at_prune_mask_f32(at_ctx* ctx, const float* x, int64_t n, int d, 
 
 // fp16-split filter: rows swept / rows handed to the fp32 redo since the last reset.
 extern "C" int at_filter_stats(at_ctx* ctx, int64_t* rows, int64_t* listed, double* sweep_ms, int64_t* sweeps,
-                               int reset) {
+                               int64_t* tiles, int64_t* refined, int reset) {
     AT_REQUIRE(ctx && rows && listed, "at_filter_stats: bad arguments");
     *rows = ctx->filter_rows;
     *listed = ctx->filter_listed;
     if (sweep_ms) *sweep_ms = ctx->filter_ms;
     if (sweeps) *sweeps = ctx->filter_launches;
+    if (tiles) *tiles = ctx->filter_tiles;
+    if (refined) *refined = ctx->filter_refined;
     if (reset) {
-        ctx->filter_rows = ctx->filter_listed = ctx->filter_launches = 0;
+        ctx->filter_rows = ctx->filter_listed = ctx->filter_launches = ctx->filter_tiles = ctx->filter_refined = 0;
         ctx->filter_ms = 0.0;
     }
     return AT_OK;

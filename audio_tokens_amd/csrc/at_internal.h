@@ -41,6 +41,7 @@ struct at_ctx {
     hipEvent_t filter_ev[2];             // around the stage-1 kernel of exact calls (created on first use)
     double filter_ms;                    // summed stage-1 kernel time, over filter_launches launches
     int64_t filter_launches;
+    int64_t filter_tiles, filter_refined;  // 32x32 tiles multiplied (hi*hi) / refined (lo products too), exact calls
     hipStream_t side_stream;             // centroid_accum: long member lists beside the short ones
     hipEvent_t side_ev[2];
 };

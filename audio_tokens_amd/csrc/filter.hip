@@ -253,9 +253,11 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
             i2[b] = j2;
         }
     };
+    unsigned n_hh = 0, n_ref = 0;  // statistics: tiles multiplied (hi*hi) / refined with the lo products
     auto compute_group = [&](int e, const half8 (&ah)[NS], const f32x4 (&cnv)[4]) {
         const int g = e & 511;
         const bool need0 = (e >> 9) & 1, need1 = (e >> 10) & 1;  // wave-uniform
+        n_hh += (unsigned)need0 + (unsigned)need1;
         f32x16 a0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         f32x16 a1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         bool pass0 = false, pass1 = false;
@@ -284,6 +286,7 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
 #pragma unroll
             for (int s = 0; s < NS; s++) al[s] = fr[s * 64 + lane];
         }
+        n_ref += (unsigned)pass0 + (unsigned)pass1;
         if (pass0) refine(0, g, a0, ah, al, cnv);
         if (pass1) refine(1, g, a1, ah, al, cnv);
     };
@@ -310,6 +313,10 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
         compute_group(e1, ahB, cnB);
     }
 
+    if (lane == 0) {  // statistics only, spread over 16 slot pairs
+        atomicAdd(&misc[4 + 2 * (blockIdx.x & 15)], n_hh);
+        atomicAdd(&misc[5 + 2 * (blockIdx.x & 15)], n_ref);
+    }
     auto slot_id = [&](unsigned slot) {
         return slot == NONE ? NONE
                             : reinterpret_cast<const unsigned*>(img + (size_t)(slot >> 5) * GB + misc_off(D) + 128)[slot & 31];
@@ -591,7 +598,7 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
     if (!img) return AT_E_NOMEM;
     hipLaunchKernelGGL(prep_centroids_f16_kernel, dim3(ng), dim3(WG), 0, stream, c, k, d, cperm, img);
     AT_LAUNCH_CHECK();
-    AT_HIP(hipMemsetAsync(misc, 0, 2 * sizeof(unsigned), stream));
+    AT_HIP(hipMemsetAsync(misc, 0, 64 * sizeof(unsigned), stream));  // max|c|^2, list length, statistics
     hipLaunchKernelGGL(max_sqnorm_bits_kernel, dim3((k + WG - 1) / WG), dim3(WG), 0, stream, c, k, d, misc);
     AT_LAUNCH_CHECK();
     float ta = 0.0f, tb = 0.0f, ra = 0.0f, rb = 0.0f;
@@ -605,7 +612,8 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
     AT_REQUIRE(d == 64, "at_filter_sweep: d must be 64");
     if (collect) {  // exact calls synchronise anyway: time the kernel for at_filter_stats
         for (int i = 0; i < 2; i++)
-            if (!ctx->filter_ev[i]) AT_HIP(hipEventCreate(&ctx->filter_ev[i]));
+            if (!ctx->filter_ev[i])  // no system-scope release at the event: it would charge an L2 write-back to the kernel
+                AT_HIP(hipEventCreateWithFlags(&ctx->filter_ev[i], hipEventDisableSystemFence));
         AT_HIP(hipEventRecord(ctx->filter_ev[0], stream));
     }
     hipLaunchKernelGGL((assign_f16filter_kernel<64, NB>), grid, dim3(64), 0, stream, x, (long)n, img, ng, order, bd,

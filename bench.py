@@ -141,7 +141,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     trace, be.assign_trace = be.assign_trace, None
-    f_rows, f_listed, f_ms, f_sweeps = be.filter_stats(timing=True)   # timed steps only
+    f_rows, f_listed, f_ms, f_sweeps, f_tiles, f_refined = be.filter_stats(timing=True)   # timed steps only
     needed, total = be.prune_stats()
     stage = pipe.run(wave_tr, wave_va, timing=True).stage_seconds  # one extra, untimed, per-stage split
 
@@ -170,7 +170,7 @@ def main():
     kinds = {kd: agg(kd) for kd in ("pruned", "coarse", "plain", "hinted")}
     filtered = f_sweeps > 0
     names = {"pruned": ("at_assign_pruned_f32 exact call: assign_f16filter_kernel<64,2> + exact_dist_visit_kernel + fp32 redo "
-                        "(assign_mfma_pruned_reg_kernel<64,2>) of the listed rows") if filtered
+                        "of the listed rows (exact_rows_kernel<64>)") if filtered
              else "assign_mfma_pruned_reg_kernel<64,2> (at_assign_pruned_f32, exact mode)",
              "coarse": ("assign_f16filter_kernel<64,2>" if filtered else "assign_mfma_pruned_reg_kernel<64,2>") + " (guess generator mode)",
              "plain": "assign_mfma_kernel<64,2,4,DMA,2> (at_assign_f32)",
@@ -200,7 +200,9 @@ def main():
         rows_settled = f_rows - f_listed
         flop = 2.0 * args.n_mels * args.vocab * rows_settled
         achieved = flop / (f_ms * 1e-3) / 1e12 if f_ms > 0 else 0.0
-        exec_f16 = achieved * 3.0 * exec_frac if exec_frac is not None else None
+        ns = args.n_mels // 16
+        mfma_issued = f_tiles * ns + f_refined * 2 * ns            # v_mfma_f32_32x32x16_f16 instructions
+        exec_f16 = mfma_issued * 32768.0 / (f_ms * 1e-3) / 1e12 if f_ms > 0 else None
         roofline = {
             "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
@@ -209,6 +211,7 @@ def main():
             "share_of_step_time": (f_ms * 1e-3) / elapsed if elapsed > 0 else None,
             "rows_listed_for_fp32_redo_fraction": f_listed / f_rows if f_rows else None,
             "accumulators_computed_fraction": exec_frac,
+            "tiles_refined_with_lo_products_fraction": f_refined / f_tiles if f_tiles else None,
             "executed_mfma_dtype": "f16 (fp32 accumulate)", "executed_tflops": exec_f16,
             "executed_peak": PEAK_F16_MFMA_TFLOPS,
             "executed_frac": exec_f16 / PEAK_F16_MFMA_TFLOPS if exec_f16 is not None else None,
@@ -218,9 +221,9 @@ def main():
                            "share_of_step_time": (D["ms"] * 1e-3) / elapsed if elapsed > 0 else None},
             "note": ("achieved/frac are ALGORITHMIC fp32 flop (2*d*k per row = the dense IndexFlatL2 search the contract "
                      "specifies) against the fp32 MFMA peak; > 1 because (a) a rounding-safe triangle-inequality bound skips "
-                     "most 32x32 accumulators and (b) the surviving ones are evaluated as three fp16 MFMAs whose error is "
-                     "bounded a priori, a row being accepted only when its runner-up is provably out of reach of the fp32 "
-                     "contract; the other rows are redone in fp32.  ids/dist/centroids are bit-identical to the dense fp32 "
+                     "most 32x32 accumulators and (b) the surviving ones are evaluated with fp16 MFMAs (hi*hi first, the two lo "
+                     "products only for tiles that can matter) whose error is bounded a priori, a row being accepted only when "
+                     "its runner-up is provably out of reach of the fp32 contract; the other rows are redone in fp32.  ids/dist/centroids are bit-identical to the dense fp32 "
                      "sweep (tests/test_gpu_ops.py::test_assign_pruned_is_exact, test_filter_*).  executed_* prices the "
                      "fp16 MFMA flop actually issued against the dense fp16 peak.  The dense fp32 kernel "
                      "(assign_mfma_kernel) runs at 132 TFLOP/s = 84 % of the fp32 peak, see profiles/."),

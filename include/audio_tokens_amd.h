@@ -171,10 +171,12 @@ int at_prune_mask_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float
  * provably out of reach of the fp32 contract), the remaining rows are redone by the fp32 sweep, so
  * ids/dist are bit-identical to mode without the flag.  With the flag the call synchronises the
  * stream once (it reads the number of rows to redo).  at_filter_stats reports rows swept / redone
- * and the summed HIP-event time of the stage-1 kernel over `sweeps` exact calls (NULL to skip);
+ * the summed HIP-event time of the stage-1 kernel over `sweeps` exact calls, and how many 32x32
+ * tiles it multiplied (hi*hi: d/16 MFMAs) / refined (2 d/16 more) (NULL to skip any of them);
  * at_filter_probe_f32 is a test hook (stage 1 only; approx[2i], approx[2i+1] = approximate
  * |c|^2 - 2 x.c of the winner and its gap to the runner-up). */
-int at_filter_stats(at_ctx* ctx, int64_t* rows, int64_t* listed, double* sweep_ms, int64_t* sweeps, int reset);
+int at_filter_stats(at_ctx* ctx, int64_t* rows, int64_t* listed, double* sweep_ms, int64_t* sweeps,
+                    int64_t* tiles, int64_t* refined, int reset);
 int at_filter_probe_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
                         const uint32_t* order, const uint32_t* hint_sorted, const int32_t* cperm, int ng,
                         const float* dmin, int64_t* ids, float* approx, int64_t* listed, void* stream);
