@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(WG) max_sqnorm_bits_kernel(const float* __rest
 }
 
 // One wavefront per workgroup, the structure of assign_mfma_pruned_reg_kernel (assign.hip): the wave
-// walks the groups its 64 rows (two 32-row tiles) need; the hi fragments of the next group are
+// walks the groups its 32*NB rows (NB = 4 tiles of 32, handled in pairs) need; the hi fragments of the next group are
 // fetched into registers while the current one multiplies.  The needed groups are compacted once
 // into a small LDS list (group | tile bits), so the walk costs a handful of scalar instructions per
 // group.  misc[0] = max |c|^2 bits, misc[1] = ambiguous-row counter.
@@ -125,10 +125,11 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
                         float tau_b, float rho_a, float rho_b, int screen, int collect, long* __restrict__ ids,
                         uint32_t* __restrict__ amb_list, uint32_t* __restrict__ amb_aux,
                         float* __restrict__ approx_out) {
-    static_assert(NB == 2, "written for two 32-row tiles per wave");
+    static_assert(NB == 2 || NB == 4, "tiles are processed in pairs");
     constexpr int NS = D / 16;
     constexpr size_t GB = group_bytes(D);
     __shared__ unsigned short glist[512];
+    __shared__ half8 xl_lds[NB][D / 16][64];  // lo parts of the rows: only the rare refined tiles read them
 
     const int lane = threadIdx.x;
     const int j = lane & 31;
@@ -138,38 +139,40 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
     const float cnmax = __uint_as_float(misc[0]);
     const bool c_bad = !(cnmax < RANGE_SQ);
 
-    half8 xh[NB][NS], xl[NB][NS];
+    half8 xh[NB][NS];
     // per row (lane-local; the two half-waves hold disjoint centroids of the same row): the three
     // smallest approximate distances seen and the slots of the two smallest
     float b1[NB], b2[NB], b3[NB], tau[NB], rho[NB];
     unsigned i1[NB], i2[NB];
     bool bad[NB];
-    long rowid[NB];
+    unsigned rowid[NB];
 #pragma unroll
     for (int b = 0; b < NB; b++) {
         long pos = pos0 + 32 * b + j;
         if (pos >= n) pos = n - 1;
-        const long r = (long)order[pos];
+        const unsigned r = order[pos];
         rowid[b] = r;
-        const f32x4* p = reinterpret_cast<const f32x4*>(X + r * D);
+        const f32x4* p = reinterpret_cast<const f32x4*>(X + (size_t)r * D);
         float part = 0.0f;
 #pragma unroll
         for (int s = 0; s < NS; s++) {
             const f32x4 u = p[4 * s + 2 * h], v = p[4 * s + 2 * h + 1];
+            half8 xlo;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 part = __builtin_fmaf(u[e], u[e], part);
                 const _Float16 hu = (_Float16)u[e];
                 xh[b][s][e] = hu;
-                xl[b][s][e] = (_Float16)(u[e] - (float)hu);
+                xlo[e] = (_Float16)(u[e] - (float)hu);
             }
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 part = __builtin_fmaf(v[e], v[e], part);
                 const _Float16 hv = (_Float16)v[e];
                 xh[b][s][4 + e] = hv;
-                xl[b][s][4 + e] = (_Float16)(v[e] - (float)hv);
+                xlo[4 + e] = (_Float16)(v[e] - (float)hv);
             }
+            xl_lds[b][s][lane] = xlo;
         }
         const float nrm = part + __shfl_xor(part, 32);
         tau[b] = __builtin_fmaf(tau_a, nrm * 1.001f + cnmax, tau_b);
@@ -234,7 +237,7 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
 #pragma unroll
         for (int s = 0; s < NS; s++) {
             a = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], xh[b][s], a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xl[b][s], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xl_lds[b][s][lane], a, 0, 0, 0);
         }
         float P[16];
 #pragma unroll
@@ -256,39 +259,48 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
     unsigned n_hh = 0, n_ref = 0;  // statistics: tiles multiplied (hi*hi) / refined with the lo products
     auto compute_group = [&](int e, const half8 (&ah)[NS], const f32x4 (&cnv)[4]) {
         const int g = e & 511;
-        const bool need0 = (e >> 9) & 1, need1 = (e >> 10) & 1;  // wave-uniform
-        n_hh += (unsigned)need0 + (unsigned)need1;
-        f32x16 a0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        f32x16 a1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        bool pass0 = false, pass1 = false;
-        if (need0 && need1) {  // the common case: two independent accumulator chains, interleaved
-#pragma unroll
-            for (int s = 0; s < NS; s++) {
-                a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[0][s], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[1][s], a1, 0, 0, 0);
-            }
-            const float m0 = screen_min(a0, cnv), m1 = screen_min(a1, cnv);
-            pass0 = __builtin_amdgcn_ballot_w64(m0 < b3[0] + rho[0]) != 0;
-            pass1 = __builtin_amdgcn_ballot_w64(m1 < b3[1] + rho[1]) != 0;
-        } else if (need0) {
-#pragma unroll
-            for (int s = 0; s < NS; s++) a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[0][s], a0, 0, 0, 0);
-            pass0 = __builtin_amdgcn_ballot_w64(screen_min(a0, cnv) < b3[0] + rho[0]) != 0;
-        } else {
-#pragma unroll
-            for (int s = 0; s < NS; s++) a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[1][s], a1, 0, 0, 0);
-            pass1 = __builtin_amdgcn_ballot_w64(screen_min(a1, cnv) < b3[1] + rho[1]) != 0;
-        }
-        if (!(pass0 || pass1)) return;
         half8 al[NS];
-        {
-            const half8* fr = reinterpret_cast<const half8*>(img + (size_t)g * GB + lo_off(D));
+        bool have_al = false;
 #pragma unroll
-            for (int s = 0; s < NS; s++) al[s] = fr[s * 64 + lane];
+        for (int pr = 0; pr < NB / 2; pr++) {  // tiles in pairs: two independent accumulator chains, interleaved
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int t0 = 2 * pr, t1 = 2 * pr + 1;
+            const bool need0 = (e >> (9 + t0)) & 1, need1 = (e >> (9 + t1)) & 1;  // wave-uniform
+            if (!(need0 || need1)) continue;
+            n_hh += (unsigned)need0 + (unsigned)need1;
+            f32x16 a0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            f32x16 a1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            bool pass0 = false, pass1 = false;
+            if (need0 && need1) {
+#pragma unroll
+                for (int s = 0; s < NS; s++) {
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[t0][s], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[t1][s], a1, 0, 0, 0);
+                }
+                const float m0 = screen_min(a0, cnv), m1 = screen_min(a1, cnv);
+                pass0 = __builtin_amdgcn_ballot_w64(m0 < b3[t0] + rho[t0]) != 0;
+                pass1 = __builtin_amdgcn_ballot_w64(m1 < b3[t1] + rho[t1]) != 0;
+            } else if (need0) {
+#pragma unroll
+                for (int s = 0; s < NS; s++) a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[t0][s], a0, 0, 0, 0);
+                pass0 = __builtin_amdgcn_ballot_w64(screen_min(a0, cnv) < b3[t0] + rho[t0]) != 0;
+            } else {
+#pragma unroll
+                for (int s = 0; s < NS; s++) a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[t1][s], a1, 0, 0, 0);
+                pass1 = __builtin_amdgcn_ballot_w64(screen_min(a1, cnv) < b3[t1] + rho[t1]) != 0;
+            }
+            if (!(pass0 || pass1)) continue;
+            if (!have_al) {
+                const half8* fr = reinterpret_cast<const half8*>(img + (size_t)g * GB + lo_off(D));
+#pragma unroll
+                for (int s = 0; s < NS; s++) al[s] = fr[s * 64 + lane];
+                have_al = true;
+            }
+            n_ref += (unsigned)pass0 + (unsigned)pass1;
+            if (pass0) refine(t0, g, a0, ah, al, cnv);
+            if (pass1) refine(t1, g, a1, ah, al, cnv);
         }
-        n_ref += (unsigned)pass0 + (unsigned)pass1;
-        if (pass0) refine(0, g, a0, ah, al, cnv);
-        if (pass1) refine(1, g, a1, ah, al, cnv);
     };
 
     half8 ahA[NS], ahB[NS];
@@ -341,8 +353,8 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
             const unsigned id = slot_id(nj1);
             ids[rowid[b]] = id == NONE ? -1L : (long)id;
             if (approx_out) {  // test hook: approximate distance of the winner and the gap to the runner-up
-                approx_out[2 * rowid[b]] = n1;
-                approx_out[2 * rowid[b] + 1] = n2 - n1;
+                approx_out[2 * (size_t)rowid[b]] = n1;
+                approx_out[2 * (size_t)rowid[b] + 1] = n2 - n1;
             }
         }
         if (collect) {
@@ -606,7 +618,8 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
     filter_rho(d, &ra, &rb);
     const char* sc = std::getenv("AT_FILTER_SCREEN");  // A/B aid: 0 = always evaluate all three products
     const int screen = (sc && std::atoi(sc) == 0) ? 0 : 1;
-    constexpr int NB = 2;
+    const char* nbv = std::getenv("AT_FILTER_NB");  // A/B aid: rows per wave = 32 * NB
+    const int NB = (nbv && std::atoi(nbv) == 2) ? 2 : 4;
     const dim3 grid((unsigned)((n + 32 * NB - 1) / (32 * NB)));
     // d = 128 would need 288 vector registers for two fragment sets: it stays on the fp32 sweep
     AT_REQUIRE(d == 64, "at_filter_sweep: d must be 64");
@@ -616,9 +629,14 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
                 AT_HIP(hipEventCreateWithFlags(&ctx->filter_ev[i], hipEventDisableSystemFence));
         AT_HIP(hipEventRecord(ctx->filter_ev[0], stream));
     }
-    hipLaunchKernelGGL((assign_f16filter_kernel<64, NB>), grid, dim3(64), 0, stream, x, (long)n, img, ng, order, bd,
-                       mask, ngw, misc, ta, tb, ra, rb, screen, collect, reinterpret_cast<long*>(ids), amb_list, amb_aux,
-                       approx_out);
+    if (NB == 4)
+        hipLaunchKernelGGL((assign_f16filter_kernel<64, 4>), grid, dim3(64), 0, stream, x, (long)n, img, ng, order, bd,
+                           mask, ngw, misc, ta, tb, ra, rb, screen, collect, reinterpret_cast<long*>(ids), amb_list,
+                           amb_aux, approx_out);
+    else
+        hipLaunchKernelGGL((assign_f16filter_kernel<64, 2>), grid, dim3(64), 0, stream, x, (long)n, img, ng, order, bd,
+                           mask, ngw, misc, ta, tb, ra, rb, screen, collect, reinterpret_cast<long*>(ids), amb_list,
+                           amb_aux, approx_out);
     AT_LAUNCH_CHECK();
     if (collect) AT_HIP(hipEventRecord(ctx->filter_ev[1], stream));
     return AT_OK;
