@@ -297,7 +297,7 @@ class HipBackend(HostHelpers):
         fp16 filter sweep over all groups of means instead of the dense fp32 sweep."""
         n, d = x.shape
         ngm = means.shape[0]
-        if d != 64 or n < 20 or os.environ.get("AT_FILTER", "1") == "0":
+        if d not in (64, 128) or n < 20 or os.environ.get("AT_FILTER", "1") == "0":
             return self.assign(x, means, want_dist=False)[0]
         key = (n, ngm)
         if getattr(self, "_ident", (None,))[0] != key:
@@ -326,12 +326,12 @@ class HipBackend(HostHelpers):
         """mode 0: same result as assign(); `order` = visit_order(...) of the guesses.
         mode 1: best centroid among the groups named by each 32-row tile (order = visit_order of
         group ids) -- a guess generator.
-        filter (default: on at d = 64 unless AT_FILTER=0): fp16-split first stage, same bits out."""
+        filter (default: on unless AT_FILTER=0): fp16-split first stage, same bits out."""
         x, c = self._f32(x), self._f32(c)
         n, d = x.shape
         if filter is None:
             filter = os.environ.get("AT_FILTER", "1") != "0"
-        use_filter = bool(filter) and d == 64
+        use_filter = bool(filter) and d in (64, 128)
         k = c.shape[0]
         order, hint_sorted = order
         ng = cperm.numel() // 32

@@ -1267,7 +1267,7 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
     const uint32_t* order2 = order;
     const uint32_t* hint2 = hint_sorted;
     int64_t n2 = n;
-    if (filter && D == 64) {
+    if (filter) {
         // Stage 1: fp16-split filter (filter.hip) names the winner of every row whose runner-up is
         // provably out of reach and lists the others; stage 2 below redoes the listed rows with the
         // fp32 sweep.  Coarse mode (guesses only) needs neither the list nor stage 2.
@@ -1337,7 +1337,7 @@ extern "C" int at_assign_pruned_f32(at_ctx* ctx, const float* x, int64_t n, int 
     AT_REQUIRE(ctx, "at_assign_pruned_f32: ctx is null");
     AT_REQUIRE(x && c && order && hint_sorted && cperm && (dmin || (mode & 1)) && ids, "at_assign_pruned_f32: null pointer");
     AT_REQUIRE(mode >= 0 && mode <= 3, "at_assign_pruned_f32: mode must be 0..3");
-    const bool filter = (mode & 2) != 0 && d == 64;
+    const bool filter = (mode & 2) != 0;
     mode &= 1;
     AT_REQUIRE(d == 64 || d == 128, "at_assign_pruned_f32: d must be 64 or 128");
     AT_REQUIRE(n >= 20 && n < (int64_t)UINT32_MAX && k > 0 && ng > 0 && ng <= 512 && ng * 32 >= k,
@@ -1398,7 +1398,7 @@ extern "C" int at_filter_probe_f32(at_ctx* ctx, const float* x, int64_t n, int d
     hipStream_t stream = (hipStream_t)stream_;
     AT_REQUIRE(ctx && x && c && order && hint_sorted && cperm && dmin && ids && approx && listed,
                "at_filter_probe_f32: null pointer");
-    AT_REQUIRE(d == 64 && n >= 20 && n < (int64_t)UINT32_MAX && k > 0 && ng > 0 && ng <= 512 && ng * 32 >= k,
+    AT_REQUIRE((d == 64 || d == 128) && n >= 20 && n < (int64_t)UINT32_MAX && k > 0 && ng > 0 && ng <= 512 && ng * 32 >= k,
                "at_filter_probe_f32: bad sizes");
     AT_HIP(hipSetDevice(ctx->device));
     const int ngw = (ng + 31) / 32;

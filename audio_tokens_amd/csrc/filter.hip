@@ -303,26 +303,30 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
         }
     };
 
+    // Two register sets alternate; the list entries are read from LDS two groups before they are
+    // needed (as a vector register, turned into a scalar only when used), so neither the LDS round trip
+    // nor the fragment loads it addresses sit in front of a group's MFMAs.
     half8 ahA[NS], ahB[NS];
     f32x4 cnA[4], cnB[4];
-    int e0 = 0;
+    int e0 = -1, e1 = -1;
     if (cnt > 0) {
         e0 = entry(0);
         load_group(e0 & 511, ahA, cnA);
     }
+    if (cnt > 1) e1 = entry(1);
+    unsigned raw2 = cnt > 2 ? (unsigned)glist[2] : 0u;
     for (int i = 0; i < cnt; i += 2) {
-        int e1 = -1;
-        if (i + 1 < cnt) {
-            e1 = entry(i + 1);
-            load_group(e1 & 511, ahB, cnB);
-        }
+        if (e1 >= 0) load_group(e1 & 511, ahB, cnB);
+        const unsigned raw3 = i + 3 < cnt ? (unsigned)glist[i + 3] : 0u;
         compute_group(e0, ahA, cnA);
         if (e1 < 0) break;
-        if (i + 2 < cnt) {
-            e0 = entry(i + 2);
-            load_group(e0 & 511, ahA, cnA);
-        }
+        const int e0n = i + 2 < cnt ? __builtin_amdgcn_readfirstlane((int)raw2) : -1;
+        if (e0n >= 0) load_group(e0n & 511, ahA, cnA);
+        const unsigned raw4 = i + 4 < cnt ? (unsigned)glist[i + 4] : 0u;
         compute_group(e1, ahB, cnB);
+        e0 = e0n;
+        e1 = i + 3 < cnt ? __builtin_amdgcn_readfirstlane((int)raw3) : -1;
+        raw2 = raw4;
     }
 
     if (lane == 0) {  // statistics only, spread over 16 slot pairs
@@ -621,15 +625,18 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
     const char* nbv = std::getenv("AT_FILTER_NB");  // A/B aid: rows per wave = 32 * NB
     const int NB = (nbv && std::atoi(nbv) == 2) ? 2 : 4;
     const dim3 grid((unsigned)((n + 32 * NB - 1) / (32 * NB)));
-    // d = 128 would need 288 vector registers for two fragment sets: it stays on the fp32 sweep
-    AT_REQUIRE(d == 64, "at_filter_sweep: d must be 64");
+    AT_REQUIRE(d == 64 || d == 128, "at_filter_sweep: d must be 64 or 128");
     if (collect) {  // exact calls synchronise anyway: time the kernel for at_filter_stats
         for (int i = 0; i < 2; i++)
             if (!ctx->filter_ev[i])  // no system-scope release at the event: it would charge an L2 write-back to the kernel
                 AT_HIP(hipEventCreateWithFlags(&ctx->filter_ev[i], hipEventDisableSystemFence));
         AT_HIP(hipEventRecord(ctx->filter_ev[0], stream));
     }
-    if (NB == 4)
+    if (d == 128)  // two tiles per wave: the fragment sets of d = 128 leave no registers for four
+        hipLaunchKernelGGL((assign_f16filter_kernel<128, 2>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, x, (long)n,
+                           img, ng, order, bd, mask, ngw, misc, ta, tb, ra, rb, screen, collect,
+                           reinterpret_cast<long*>(ids), amb_list, amb_aux, approx_out);
+    else if (NB == 4)
         hipLaunchKernelGGL((assign_f16filter_kernel<64, 4>), grid, dim3(64), 0, stream, x, (long)n, img, ng, order, bd,
                            mask, ngw, misc, ta, tb, ra, rb, screen, collect, reinterpret_cast<long*>(ids), amb_list,
                            amb_aux, approx_out);

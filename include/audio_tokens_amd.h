@@ -166,7 +166,7 @@ int at_prune_mask_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float
                       const uint32_t* order, const uint32_t* hint_sorted, int ng,
                       const float* dmin_or_null, int mode, void* stream);
 
-/* The exact sweeps above accept mode | 2 (d = 64): stage 1 is then the fp16-split filter
+/* The exact sweeps above accept mode | 2: stage 1 is then the fp16-split filter
  * (csrc/filter.hip: three fp16 MFMAs per fp32 one, winner accepted only when the runner-up is
  * provably out of reach of the fp32 contract), the remaining rows are redone by the fp32 sweep, so
  * ids/dist are bit-identical to mode without the flag.  With the flag the call synchronises the

@@ -112,7 +112,7 @@ def test_assign_pruned_is_exact(be, oracle, monkeypatch, n, d, k, lds_kernel):
     }
     for name, (hint, hd) in cases.items():
         order = be.visit_order(hint.contiguous(), hd, k)
-        for flt in ((False, True) if d == 64 else (False,)):       # fp32 sweep alone / behind the fp16-split filter
+        for flt in (False, True):                                   # fp32 sweep alone / behind the fp16-split filter
             ids, dis = be.assign_pruned(xt, ct, order, cperm, dmin, filter=flt)
             assert np.array_equal(ids.cpu().numpy(), ids_o), f"hint={name} filter={flt}: {(ids.cpu().numpy() != ids_o).sum()} ids differ"
             assert np.array_equal(bits(dis.cpu().numpy()), bits(dis_o)), (name, flt)
@@ -135,13 +135,14 @@ def _filter_eps(d, H):
     return H * (34 * m * u * 1.01 + 3 * 2.0 ** -22 + d * u * 1.01 + 2 * u + 2 * q) + 4 * q
 
 
-@pytest.mark.parametrize("scale_x,scale_c", [(1.0, 1.0), (30.0, 0.02), (0.003, 7.0), (1000.0, 1000.0)])
-def test_filter_error_bound(be, oracle, scale_x, scale_c):
+@pytest.mark.parametrize("scale_x,scale_c,d", [(1.0, 1.0, 64), (30.0, 0.02, 64), (0.003, 7.0, 64), (1000.0, 1000.0, 64),
+                                               (1.0, 1.0, 128), (0.01, 50.0, 128)])
+def test_filter_error_bound(be, oracle, scale_x, scale_c, d):
     """Stage 1 alone: the approximate distances stay inside the bound the acceptance test assumes
     (measured against float64), on unit rows and on badly scaled ones, with sign-alternating data
     that makes the inner products cancel."""
     rng = np.random.default_rng(17)
-    n, d, k = 40000, 64, 2048
+    n, k = 40000, 2048
     x = (rng.standard_normal((n, d)) * rng.choice([1e-3, 1.0], (n, d), p=[0.3, 0.7])).astype(np.float32)
     x = oracle.l2norm_rows(x) * np.float32(scale_x)
     c = oracle.l2norm_rows((x[rng.integers(0, n, k)] / np.float32(scale_x) + 0.02 * rng.standard_normal((k, d))).astype(np.float32))
