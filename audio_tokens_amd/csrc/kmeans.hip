@@ -148,7 +148,9 @@ __global__ void __launch_bounds__(WG) centroid_accum_long_kernel(const float* __
                                                                  uint32_t long_list,
                                                                  float* __restrict__ sums,
                                                                  float* __restrict__ counts) {
-    __shared__ __attribute__((aligned(16))) float4 ring[2][LONG_CHUNK];
+    // feature-major ring: ring[buffer][feature][member], so an adder lane reads four consecutive members of
+    // its feature with one 16-byte LDS read
+    __shared__ __attribute__((aligned(16))) float ring[2][4][LONG_CHUNK];
     const int c = blockIdx.x;
     const int piece = blockIdx.y;  // features 4*piece .. 4*piece+3
     const uint32_t beg = offsets[c], end = offsets[c + 1];
@@ -179,7 +181,12 @@ __global__ void __launch_bounds__(WG) centroid_accum_long_kernel(const float* __
 #pragma unroll
         for (int u = 0; u < LONG_PER_THREAD; u++) {
             const uint32_t e = t + u * LONG_LOADERS;
-            if (e < cnt) ring[ch & 1][e] = v[u];
+            if (e < cnt) {
+                ring[ch & 1][0][e] = v[u].x;
+                ring[ch & 1][1][e] = v[u].y;
+                ring[ch & 1][2][e] = v[u].z;
+                ring[ch & 1][3][e] = v[u].w;
+            }
         }
     };
 
@@ -190,17 +197,22 @@ __global__ void __launch_bounds__(WG) centroid_accum_long_kernel(const float* __
         if (!adder) {
             if (ch + 1 < nchunks) stage(ch + 1);
         } else if (tid < 4) {
-            const float* src = reinterpret_cast<const float*>(ring[ch & 1]) + tid;
+            const float* src = ring[ch & 1][tid];
             const uint32_t cnt = min((uint32_t)LONG_CHUNK, len - ch * LONG_CHUNK);
             uint32_t m = 0;
             for (; m + 16 <= cnt; m += 16) {
-                float t[16];
+                float4 t[4];
 #pragma unroll
-                for (int u = 0; u < 16; u++) t[u] = src[4 * (m + u)];
+                for (int u = 0; u < 4; u++) t[u] = *reinterpret_cast<const float4*>(src + m + 4 * u);
 #pragma unroll
-                for (int u = 0; u < 16; u++) acc += t[u];
+                for (int u = 0; u < 4; u++) {
+                    acc += t[u].x;
+                    acc += t[u].y;
+                    acc += t[u].z;
+                    acc += t[u].w;
+                }
             }
-            for (; m < cnt; m++) acc += src[4 * m];
+            for (; m < cnt; m++) acc += src[m];
         }
         __syncthreads();
     }
