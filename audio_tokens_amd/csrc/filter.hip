@@ -117,7 +117,7 @@ __device__ __forceinline__ float min16(const float (&p)[16]) {
     return __builtin_fminf(__builtin_fminf(a, b), __builtin_fminf(c, d));
 }
 
-template <int D, int NB>
+template <int D, int NB, bool GUESS>
 __global__ void __launch_bounds__(64, 2)
 assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char* __restrict__ img, int ng,
                         const uint32_t* __restrict__ order, const float* __restrict__ bd_in,
@@ -256,6 +256,22 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
             i2[b] = j2;
         }
     };
+    auto best_only = [&](int b, int g, const f32x16& a, const f32x4 (&cnv)[4]) {
+        float P[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) P[r] = __builtin_fmaf(-2.0f, a[r], cnv[r >> 2][r & 3]);
+        if (__builtin_amdgcn_ballot_w64(min16(P) < b1[b]) != 0) {
+            float v1 = b1[b];
+            unsigned lr = 0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                lr = P[r] < v1 ? (unsigned)r : lr;
+                v1 = __builtin_fminf(v1, P[r]);
+            }
+            if (v1 < b1[b]) i1[b] = (unsigned)g * 32u + 4u * h + (lr & 3u) + 8u * (lr >> 2);
+            b1[b] = v1;
+        }
+    };
     unsigned n_hh = 0, n_ref = 0;  // statistics: tiles multiplied (hi*hi) / refined with the lo products
     auto compute_group = [&](int e, const half8 (&ah)[NS], const f32x4 (&cnv)[4]) {
         const int g = e & 511;
@@ -272,6 +288,37 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
             f32x16 a0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             f32x16 a1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             bool pass0 = false, pass1 = false;
+            if constexpr (GUESS) {
+                // guess generator (coarse passes): nobody has a running best worth screening against, so
+                // every tile gets all three products (a guess made from hi*hi alone is measurably worse and
+                // costs the exact pass more than it saves here), but only the best candidate is kept
+                if (!have_al) {
+                    const half8* fr = reinterpret_cast<const half8*>(img + (size_t)g * GB + lo_off(D));
+#pragma unroll
+                    for (int s = 0; s < NS; s++) al[s] = fr[s * 64 + lane];
+                    have_al = true;
+                }
+                n_ref += (unsigned)need0 + (unsigned)need1;
+#pragma unroll
+                for (int s = 0; s < NS; s++) {
+                    if (need0) {
+                        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], xh[t0][s], a0, 0, 0, 0);
+                        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xl_lds[t0][s][lane], a0, 0, 0, 0);
+                    }
+                    if (need1) {
+                        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], xh[t1][s], a1, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xl_lds[t1][s][lane], a1, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < NS; s++) {
+                    if (need0) a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[t0][s], a0, 0, 0, 0);
+                    if (need1) a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[t1][s], a1, 0, 0, 0);
+                }
+                if (need0) best_only(t0, g, a0, cnv);
+                if (need1) best_only(t1, g, a1, cnv);
+                continue;
+            }
             if (need0 && need1) {
 #pragma unroll
                 for (int s = 0; s < NS; s++) {
@@ -632,18 +679,24 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
                 AT_HIP(hipEventCreateWithFlags(&ctx->filter_ev[i], hipEventDisableSystemFence));
         AT_HIP(hipEventRecord(ctx->filter_ev[0], stream));
     }
-    if (d == 128)  // two tiles per wave: the fragment sets of d = 128 leave no registers for four
-        hipLaunchKernelGGL((assign_f16filter_kernel<128, 2>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, x, (long)n,
-                           img, ng, order, bd, mask, ngw, misc, ta, tb, ra, rb, screen, collect,
-                           reinterpret_cast<long*>(ids), amb_list, amb_aux, approx_out);
-    else if (NB == 4)
-        hipLaunchKernelGGL((assign_f16filter_kernel<64, 4>), grid, dim3(64), 0, stream, x, (long)n, img, ng, order, bd,
-                           mask, ngw, misc, ta, tb, ra, rb, screen, collect, reinterpret_cast<long*>(ids), amb_list,
-                           amb_aux, approx_out);
-    else
-        hipLaunchKernelGGL((assign_f16filter_kernel<64, 2>), grid, dim3(64), 0, stream, x, (long)n, img, ng, order, bd,
-                           mask, ngw, misc, ta, tb, ra, rb, screen, collect, reinterpret_cast<long*>(ids), amb_list,
-                           amb_aux, approx_out);
+#define AT_FILTER_LAUNCH(DD, NBB, GG, GRID)                                                                          \
+    hipLaunchKernelGGL((assign_f16filter_kernel<DD, NBB, GG>), GRID, dim3(64), 0, stream, x, (long)n, img, ng, order, bd, \
+                       mask, ngw, misc, ta, tb, ra, rb, screen, collect, reinterpret_cast<long*>(ids), amb_list, amb_aux, \
+                       approx_out)
+    // exact calls (collect) and guess generators are separate instantiations: the guess path's code
+    // would otherwise cost the exact sweep registers it does not have
+    const dim3 grid64((unsigned)((n + 63) / 64));
+    if (d == 128) {  // two tiles per wave: the fragment sets of d = 128 leave no registers for four
+        if (collect) AT_FILTER_LAUNCH(128, 2, false, grid64);
+        else AT_FILTER_LAUNCH(128, 2, true, grid64);
+    } else if (NB == 4) {
+        if (collect) AT_FILTER_LAUNCH(64, 4, false, grid);
+        else AT_FILTER_LAUNCH(64, 4, true, grid);
+    } else {
+        if (collect) AT_FILTER_LAUNCH(64, 2, false, grid);
+        else AT_FILTER_LAUNCH(64, 2, true, grid);
+    }
+#undef AT_FILTER_LAUNCH
     AT_LAUNCH_CHECK();
     if (collect) AT_HIP(hipEventRecord(ctx->filter_ev[1], stream));
     return AT_OK;
