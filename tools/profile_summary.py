@@ -16,7 +16,8 @@ exact = []
 for i, r in enumerate(tr):
     if "f16filter" not in r["Kernel_Name"]:
         continue
-    shapes[int(r["Grid_Size_X"])].append(dur(r))
+    if "false>" in r["Kernel_Name"]:
+        shapes[int(r["Grid_Size_X"])].append(dur(r))
     j = i + 1
     while j < len(tr) and ("rocclr" in tr[j]["Kernel_Name"]):   # skip the runtime's copy / fill kernels
         j += 1
@@ -31,7 +32,7 @@ with open(out, "w") as f:
     f.write(f"bench line of this run: {d['value']:.4g} frames/s, {d['ms_per_step']:.1f} ms/step\n\n")
     f.write("assign_f16filter_kernel<64,4,false>, the roofline kernel of bench.py:\n")
     for k, v in sorted(shapes.items()):
-        f.write(f"  launches of {k:>9d} rows: {len(v):4d}, avg {sum(v) / len(v):9.1f} us\n")
+        f.write(f"  launches of {2 * k:>9d} rows ({k} threads, one wave per 128 rows): {len(v):4d}, avg {sum(v) / len(v):9.1f} us\n")
     f.write(f"  exact-mode launches (followed by exact_dist_visit_kernel / exact_rows_kernel; 62 per pipeline run: 60 Lloyd sweeps of\n"
             f"  2 097 152 rows + the tokenise sweeps of 38.8 M and 4.3 M rows): {len(exact)} in this trace, avg {sum(exact) / max(1, len(exact)):.1f} us\n"
             f"  bench.py roofline.avg_launch_ms (HIP events around the same kernel, exact launches of the 3 timed steps): "
