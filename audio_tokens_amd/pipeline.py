@@ -13,6 +13,12 @@ quantities from waveforms that are already resident in HBM, which is what bench.
 With torch.distributed initialised (`distributed=True`) every rank holds a contiguous block of the
 clips of every file batch; log-mel and tokenise need no communication and k-means exchanges the
 per-cluster partial sums/counts once per Lloyd iteration (ops.Kmeans).
+
+`run_streaming` is the same computation for clip sets that do not fit in HBM (BASELINE.json's
+configs[4]: 2 M clips = 1.76 TB of waveform per node): waveforms stay in host memory and cross to
+the device in chunks through two pinned staging buffers on a copy stream, overlapped with the
+kernels; frames exist only for the k-means batch being trained and are recomputed for tokenise
+(log-mel costs less than keeping 3.5 G frames around), tokens return to the host chunk by chunk.
 """
 from __future__ import annotations
 
@@ -105,4 +111,102 @@ class DevicePipeline:
             tok_va, _ = index.assign(frames_va, want_dist=False)
         sync(); secs["tokenize"] = time.perf_counter() - t0
 
+        return PipelineResult(centroids, tok_tr, tok_va, T, secs, stats)
+
+    # -- host-resident inputs ------------------------------------------------------------------
+    class _Feeder:
+        """Chunks of a host [n_clips, L] float32 tensor on the device, double buffered: while the
+        kernels of chunk i run on the compute stream, chunk i+1 is copied host -> pinned staging ->
+        device on a copy stream.  A staging/device buffer pair is reused only after the kernels
+        that read it have been waited for (events)."""
+
+        def __init__(self, be, wave_host, chunk_clips):
+            self.be, self.wave, self.chunk = be, wave_host, int(chunk_clips)
+            L = wave_host.shape[1]
+            self.pinned = wave_host.is_pinned()
+            self.copy_stream = torch.cuda.Stream(device=be.device)
+            self.dev = [torch.empty((self.chunk, L), dtype=torch.float32, device=be.device) for _ in range(2)]
+            self.stage = None if self.pinned else [torch.empty((self.chunk, L), dtype=torch.float32).pin_memory()
+                                                   for _ in range(2)]
+            self.copied = [torch.cuda.Event() for _ in range(2)]   # H2D of the slot finished
+            self.consumed = [None, None]                             # kernels reading the slot finished
+
+        def _issue(self, slot, c0, c1):
+            n = c1 - c0
+            if self.consumed[slot] is not None:
+                self.copy_stream.wait_event(self.consumed[slot])
+            with torch.cuda.stream(self.copy_stream):
+                src = self.wave[c0:c1]
+                if not self.pinned:
+                    if self.consumed[slot] is not None:
+                        self.copied[slot].synchronize()   # the previous H2D out of this staging buffer is done
+                    self.stage[slot][:n].copy_(src)
+                    src = self.stage[slot][:n]
+                self.dev[slot][:n].copy_(src, non_blocking=True)
+                self.copied[slot].record(self.copy_stream)
+
+        def chunks(self, c_begin, c_end):
+            """Yields (first clip, device view [n, L]) for the clips [c_begin, c_end)."""
+            bounds = [(c, min(c_end, c + self.chunk)) for c in range(c_begin, c_end, self.chunk)]
+            if not bounds:
+                return
+            self._issue(0, *bounds[0])
+            for i, (c0, c1) in enumerate(bounds):
+                slot = i & 1
+                if i + 1 < len(bounds):
+                    self._issue(slot ^ 1, *bounds[i + 1])
+                torch.cuda.current_stream(self.be.device).wait_event(self.copied[slot])
+                yield c0, self.dev[slot][:c1 - c0]
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.be.device))
+                self.consumed[slot] = ev
+
+    def run_streaming(self, wave_train_host, wave_val_host=None, chunk_clips=None, timing=False) -> PipelineResult:
+        """run() for host-resident waveforms (torch CPU tensors [n_clips, L], pinned or not).  Same
+        centroids and tokens as run() on the same clips; tokens are returned as host tensors."""
+        be = self.be
+        sync = be.synchronize if timing else (lambda: None)
+        secs = {}
+        chunk = int(chunk_clips or self.spectrogram_batch_size)
+        n_clips, L = wave_train_host.shape
+        T = be.num_frames(L, self.hop_length)
+        feed = self._Feeder(be, wave_train_host, chunk)
+
+        t0 = time.perf_counter()
+        km = Kmeans(self.n_mels, self.vocab_size, niter=self.niter, verbose=self.verbose,
+                    distributed=self.distributed, process_group=self.process_group, backend=be)
+        per_rank = max(1, self.clustering_batch_size // self.world)
+        frames = be.empty((min(per_rank, n_clips) * T, self.n_mels))     # one k-means batch at a time
+        stats = []
+        for b, b0 in enumerate(range(0, n_clips, per_rank)):
+            b1 = min(n_clips, b0 + per_rank)
+            for c0, w in feed.chunks(b0, b1):
+                be.logmel(w, self.sample_rate, self.n_fft, self.hop_length, self.n_mels, frame_major=True,
+                          l2norm=True, out=frames[(c0 - b0) * T:(c0 - b0 + w.shape[0]) * T])
+            x = frames[:(b1 - b0) * T]
+            km.train(x) if b == 0 else km.train(x, init_centroids=km.centroids_device)
+            stats.append(km.iteration_stats)
+        centroids = be.l2norm_rows(km.centroids_device)
+        sync(); secs["logmel+kmeans"] = time.perf_counter() - t0
+
+        t0 = time.perf_counter()
+        index = IndexFlatL2(self.n_mels, backend=be)
+        index.add(centroids)
+
+        def tokenise(wave_host, feeder):
+            n = wave_host.shape[0]
+            out = torch.empty((n * T,), dtype=torch.int64).pin_memory()
+            for c0, w in feeder.chunks(0, n):
+                fr = be.logmel(w, self.sample_rate, self.n_fft, self.hop_length, self.n_mels, frame_major=True,
+                               l2norm=True, out=frames[:w.shape[0] * T] if w.shape[0] * T <= frames.shape[0] else None)
+                tok, _ = index.assign(fr, want_dist=False)
+                out[c0 * T:(c0 + w.shape[0]) * T].copy_(tok, non_blocking=True)
+            be.synchronize()
+            return out
+
+        tok_tr = tokenise(wave_train_host, feed)
+        tok_va = torch.empty((0,), dtype=torch.int64)
+        if wave_val_host is not None and wave_val_host.shape[0] > 0:
+            tok_va = tokenise(wave_val_host, self._Feeder(be, wave_val_host, chunk))
+        sync(); secs["tokenize"] = time.perf_counter() - t0
         return PipelineResult(centroids, tok_tr, tok_va, T, secs, stats)

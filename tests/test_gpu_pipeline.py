@@ -145,3 +145,25 @@ def test_device_pipeline_matches_oracle(be, oracle):
     ids, _ = oracle.assign(frames, cent)
     assert np.array_equal(res.tokens_train.cpu().numpy(), ids[:8 * T])
     assert np.array_equal(res.tokens_val.cpu().numpy(), ids[8 * T:])
+
+
+@pytest.mark.parametrize("clips,seconds,k,batch,chunk,pinned", [(10, 3, 64, 4, 3, False), (96, 2, 1024, 40, 17, True)])
+def test_streaming_pipeline_equals_resident(be, clips, seconds, k, batch, chunk, pinned):
+    """Host-resident waveforms streamed through pinned staging buffers (configs[4]'s mode): same
+    centroids and tokens, bit for bit, as the run with everything resident in HBM."""
+    from audio_tokens_amd.pipeline import DevicePipeline
+    from audio_tokens_amd.synth import synth_clips
+    wave = synth_clips(clips, L=22050 * seconds, seed=11, device="cuda")
+    n_val = max(2, clips // 8)
+    pipe = DevicePipeline(n_mels=64, vocab_size=k, niter=4, clustering_batch_size=batch, spectrogram_batch_size=chunk + 2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = pipe.run(wave[:-n_val], wave[-n_val:])
+        host = wave.cpu()
+        if pinned:
+            host = host.pin_memory()
+        got = pipe.run_streaming(host[:-n_val], host[-n_val:], chunk_clips=chunk)
+    assert torch.equal(got.centroids.view(torch.int32), ref.centroids.view(torch.int32))
+    assert got.tokens_train.device.type == "cpu"
+    assert torch.equal(got.tokens_train, ref.tokens_train.cpu())
+    assert torch.equal(got.tokens_val, ref.tokens_val.cpu())
