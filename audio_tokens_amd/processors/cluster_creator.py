@@ -17,6 +17,7 @@ from tqdm import tqdm
 
 from ..audio_tokens_config import AudioTokensConfig
 from ..ops import Kmeans, normalize_rows
+from ..utils.prefetch import prefetch
 from ..utils.set_seed import set_seed
 
 logging.basicConfig(
@@ -52,7 +53,8 @@ class ClusterCreator:
             verbose=True,
             gpu=self.gpu,
         )
-        for i, batch in enumerate(self._batch_generator(self.config.clustering_batch_size)):
+        # the next batch of files is read while this one trains (same batches, same order)
+        for i, batch in enumerate(prefetch(self._batch_generator(self.config.clustering_batch_size))):
             batch = self.normalize_vectors(batch)
             if i == 0:
                 kmeans.train(batch)

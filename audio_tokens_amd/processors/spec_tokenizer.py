@@ -19,6 +19,7 @@ from tqdm import tqdm
 
 from ..audio_tokens_config import AudioTokensConfig
 from ..ops import IndexFlatL2, normalize_rows
+from ..utils.prefetch import prefetch
 from ..utils.set_seed import set_seed
 
 logging.basicConfig(
@@ -57,15 +58,22 @@ class SpecTokenizer:
         all_tokens = []
         spec_files = sorted(source_dir.glob("*.npy"))  # reference: Path.glob order (unspecified)
 
-        for i in tqdm(range(0, len(spec_files), self.config.tokenizer_batch_size)):
-            batch_files = spec_files[i: i + self.config.tokenizer_batch_size]
-            batch_tokens = self.process_batch(batch_files, tokenized_dir)
+        starts = range(0, len(spec_files), self.config.tokenizer_batch_size)
+
+        def load_batches():  # the next batch of files is read while this one is searched
+            for i in starts:
+                batch_files = spec_files[i: i + self.config.tokenizer_batch_size]
+                yield batch_files, [np.load(f).T for f in batch_files]
+
+        for batch_files, batch_specs in tqdm(prefetch(load_batches()), total=len(starts)):
+            batch_tokens = self.process_batch(batch_files, tokenized_dir, batch_specs)
             all_tokens.extend(batch_tokens)
 
         return all_tokens
 
-    def process_batch(self, batch_files, tokenized_dir: Path):
-        batch_specs = [np.load(spec_file).T for spec_file in batch_files]
+    def process_batch(self, batch_files, tokenized_dir: Path, batch_specs=None):
+        if batch_specs is None:  # (the reference's signature: load here)
+            batch_specs = [np.load(spec_file).T for spec_file in batch_files]
         batch_data = np.concatenate(batch_specs, axis=0)
 
         if self.config.use_convolution:

@@ -148,3 +148,18 @@ def test_sharded_kmeans_gloo_world2(case, oracle):
             warnings.simplefilter("ignore")
             r = oracle.kmeans_train(g["c_x"], 64, niter=5, init_centroids=g["c_init"], shard=shard, n_shards=2)
         assert np.array_equal(bits(res[0][1]), bits(r.centroids))
+
+
+def test_prefetch_preserves_order_and_errors():
+    from audio_tokens_amd.utils.prefetch import prefetch
+    assert list(prefetch(iter(range(7)), depth=2)) == list(range(7))
+    assert list(prefetch(iter(()))) == []
+
+    def boom():
+        yield 1
+        raise ValueError("bad file")
+
+    it = prefetch(boom())
+    assert next(it) == 1
+    with pytest.raises(ValueError, match="bad file"):
+        next(it)
