@@ -53,6 +53,7 @@ SIGNATURES = {
     "at_centroid_finalize_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "at_sum_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "at_any_nonfinite_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "at_token_histogram_i64": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
 }
 
 _lib = None

@@ -178,6 +178,16 @@ class HipBackend(HostHelpers):
                                                     orig_freq, new_freq, _ptr(out[c0:c1]), out.stride(0), self._stream()))
         return out[0] if squeeze else out
 
+    def token_histogram(self, ids, k: int) -> torch.Tensor:
+        """int64 [k] counts of the token ids (device tensor in, device tensor out)."""
+        if isinstance(ids, np.ndarray):
+            ids = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int64))
+        ids = ids.to(self.device, dtype=torch.int64).contiguous().reshape(-1)
+        counts = self.empty((k,), torch.int64)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_token_histogram_i64(self.ctx.handle, _ptr(ids), ids.numel(), k, _ptr(counts), self._stream()))
+        return counts
+
     def l2norm_rows(self, x, out=None) -> torch.Tensor:
         x = self._f32(x)
         assert x.dim() == 2

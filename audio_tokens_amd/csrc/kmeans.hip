@@ -285,6 +285,32 @@ __global__ void __launch_bounds__(WG) nonfinite_kernel(const float* __restrict__
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
+// Token histogram (spec_tokenizer.py:129-147 counts tokens with a Python
+// Counter over tokens.tolist()).  Workgroup-private counts in LDS when the vocabulary fits, one
+// global atomic per non-empty bin and workgroup afterwards.
+constexpr int HIST_LDS_BINS = 16384;
+
+__global__ void __launch_bounds__(WG) histogram_kernel(const long* __restrict__ ids, long n, int k,
+                                                       unsigned long long* __restrict__ counts) {
+    extern __shared__ unsigned int bins[];
+    const bool local = k <= HIST_LDS_BINS;
+    if (local) {
+        for (int b = threadIdx.x; b < k; b += WG) bins[b] = 0u;
+        __syncthreads();
+    }
+    for (long i = (long)blockIdx.x * WG + threadIdx.x; i < n; i += (long)gridDim.x * WG) {
+        const long t = ids[i];
+        if (t < 0 || t >= k) continue;  // rows without a token (-1) are not counted
+        if (local) atomicAdd(&bins[t], 1u);
+        else atomicAdd(&counts[t], 1ull);
+    }
+    if (local) {
+        __syncthreads();
+        for (int b = threadIdx.x; b < k; b += WG)
+            if (bins[b]) atomicAdd(&counts[b], (unsigned long long)bins[b]);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -439,6 +465,30 @@ int at_any_nonfinite_f32(at_ctx* ctx, const float* v, int64_t n, int32_t* flag, 
     int blocks = (int)((n + WG - 1) / WG);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(nonfinite_kernel, dim3(blocks), dim3(WG), 0, stream, v, (long)n, flag);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}
+
+int at_token_histogram_i64(at_ctx* ctx, const int64_t* ids, int64_t n, int k, int64_t* counts, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AT_REQUIRE(ctx && counts && k > 0 && n >= 0 && (n == 0 || ids), "at_token_histogram_i64: bad arguments");
+    AT_HIP(hipSetDevice(ctx->device));
+    AT_HIP(hipMemsetAsync(counts, 0, sizeof(int64_t) * (size_t)k, stream));
+    if (n == 0) return AT_OK;
+    int blocks = (int)((n + WG * 16 - 1) / (WG * 16));
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    const size_t lds = k <= HIST_LDS_BINS ? sizeof(unsigned int) * (size_t)k : 0;
+    if (lds > 48 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            AT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&histogram_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, HIST_LDS_BINS * 4));
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(histogram_kernel, dim3(blocks), dim3(WG), lds, stream, reinterpret_cast<const long*>(ids), (long)n, k,
+                       reinterpret_cast<unsigned long long*>(counts));
     AT_LAUNCH_CHECK();
     return AT_OK;
 }

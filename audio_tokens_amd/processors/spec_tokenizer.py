@@ -135,8 +135,17 @@ class SpecTokenizer:
         return index
 
     # ---- reporting (host side, outside the accelerated path) --------------------------------
+    def _token_counts(self, all_tokens):
+        """Counter(all_tokens); long token lists are counted on the device (at_token_histogram_i64)
+        instead of in a Python loop.  Ties then come in ascending token id, not first-seen order."""
+        if len(all_tokens) < 1_000_000:
+            return Counter(all_tokens)
+        be = self.index.backend
+        counts = be.to_host(be.token_histogram(np.asarray(all_tokens, dtype=np.int64), self.index.ntotal))
+        return Counter({int(t): int(c) for t, c in enumerate(counts) if c})
+
     def analyze_tokens(self, all_tokens):
-        token_counts = Counter(all_tokens)
+        token_counts = self._token_counts(all_tokens)
         self.logger.info(f"Total tokens: {len(all_tokens)}")
         self.logger.info(f"Unique tokens: {len(token_counts)}")
         if token_counts:
@@ -155,7 +164,7 @@ class SpecTokenizer:
         plt.close()
 
     def plot_token_distribution(self, all_tokens):
-        token_counts = Counter(all_tokens)
+        token_counts = self._token_counts(all_tokens)
         if not token_counts:
             return
         sorted_counts = sorted(token_counts.items(), key=lambda x: x[1], reverse=True)

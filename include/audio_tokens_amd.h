@@ -209,6 +209,10 @@ int at_sum_f32(at_ctx* ctx, const float* v, int64_t n, double* out, void* stream
 /* 1 if any of v[0..n) is NaN/Inf else 0, written to *flag (DEVICE int32). */
 int at_any_nonfinite_f32(at_ctx* ctx, const float* v, int64_t n, int32_t* flag, void* stream);
 
+/* counts[t] = number of i with ids[i] == t, t in [0, k) (ids outside are skipped): the token statistics of
+ * processors/spec_tokenizer.py:129-147 (a Python Counter over tokens.tolist()) without leaving the device. */
+int at_token_histogram_i64(at_ctx* ctx, const int64_t* ids, int64_t n, int k, int64_t* counts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

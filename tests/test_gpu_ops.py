@@ -382,3 +382,14 @@ def test_resample_strided_rows_and_class(be, oracle):
     assert tuple(one.shape) == (2048,)
     with pytest.raises(ValueError):
         Resample(44100.5, 22050, backend=be)
+
+
+@pytest.mark.parametrize("k", [500, 8192, 20000])
+def test_token_histogram(be, k):
+    rng = np.random.default_rng(k)
+    ids = rng.integers(-1, k, 300001)            # -1 = "no token": skipped
+    ids[:1000] = 7                                # one heavy bin
+    got = be.token_histogram(ids, k).cpu().numpy()
+    want = np.bincount(ids[ids >= 0], minlength=k)
+    assert got.dtype == np.int64 and np.array_equal(got, want)
+    assert int(be.token_histogram(np.zeros(0, np.int64), k).sum()) == 0
