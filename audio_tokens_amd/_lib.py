@@ -53,6 +53,8 @@ SIGNATURES = {
     "at_centroid_finalize_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "at_sum_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "at_any_nonfinite_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "at_centroid_accum_defer": (_i32, [_vp, _i32]),
+    "at_centroid_accum_join": (_i32, [_vp, _vp]),
     "at_token_histogram_i64": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
 }
 

@@ -404,7 +404,13 @@ class HipBackend(HostHelpers):
                                                    self._stream()))
         return out
 
-    def centroid_accum(self, x, ids, k, out=None, want_order=False):
+    def centroid_accum_join(self):
+        """Makes the current stream wait for a long-list accumulation left pending by
+        centroid_accum(..., defer_join=True).  Must precede any use of the packed partial."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_centroid_accum_join(self.ctx.handle, self._stream()))
+
+    def centroid_accum(self, x, ids, k, out=None, want_order=False, defer_join=False):
         """Packed partial result [k*d + k]: sums [k, d] followed by counts [k].  With want_order also
         (rows sorted by (id, row), their ids in that order) as int32 tensors holding uint32 bit
         patterns -- the `order` argument of assign_hinted."""
@@ -416,9 +422,11 @@ class HipBackend(HostHelpers):
         order = self.empty((n,), torch.int32) if want_order else None
         sorted_ids = self.empty((n,), torch.int32) if want_order else None
         with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_centroid_accum_defer(self.ctx.handle, 1 if defer_join else 0))
             _lib.check(self.lib.at_centroid_accum_f32(
                 self.ctx.handle, _ptr(x), n, d, _ptr(ids), k, _ptr(out), _vp(out.data_ptr() + 4 * k * d),
                 _ptr(order), _ptr(sorted_ids), self._stream()))
+            _lib.check(self.lib.at_centroid_accum_defer(self.ctx.handle, 0))
         return (out, (order, sorted_ids)) if want_order else out
 
     def centroid_finalize(self, parts, k, d):

@@ -25,6 +25,11 @@ enum at_ws_slot {
     WS_RESAMPLE_TAPS,  // resampler: polyphase filter taps [new][2*width + orig]
     WS_CENT_IMG16,     // fp16-split filter: centroid fragments (hi, lo) per group + |c|^2 + indices
     WS_FILTER_LIST,    // fp16-split filter: listed positions, sorted copy, order/hint of the redo pass
+    WS_VISIT_KEYS_A,   // at_visit_order_f32: its own sort buffers (it may run while an accumulation still reads the others)
+    WS_VISIT_KEYS_B,
+    WS_VISIT_VALS_A,
+    WS_VISIT_VALS_B,
+    WS_VISIT_TMP,
     WS_FILTER_MISC,    // fp16-split filter: max|c|^2 bits, list length; running totals for at_filter_stats
     WS_NSLOTS
 };
@@ -44,6 +49,7 @@ struct at_ctx {
     int64_t filter_tiles, filter_refined;  // 32x32 tiles multiplied (hi*hi) / refined (lo products too), exact calls
     hipStream_t side_stream;             // centroid_accum: long member lists beside the short ones
     hipEvent_t side_ev[2];
+    int defer_join, join_pending;        // at_centroid_accum_defer / at_centroid_accum_join
 };
 
 int at_fail(int code, const char* fmt, ...);

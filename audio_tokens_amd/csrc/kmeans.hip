@@ -419,7 +419,13 @@ int at_centroid_accum_f32(at_ctx* ctx, const float* x, int64_t n, int d, const i
     if (sorted_ids_out && n > 0)
         AT_HIP(hipMemcpyAsync(sorted_ids_out, sorted_keys, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice,
                               stream));
-    if (have_long) AT_HIP(hipStreamWaitEvent(stream, ctx->side_ev[1], 0));
+    // The caller's stream must not read `sums` before the side stream is done.  With order_out == the
+    // special "deferred" protocol (at_centroid_accum_join) the wait is left to the caller, who can queue
+    // independent work (the next iteration's visiting order) behind the short-list kernel meanwhile.
+    if (have_long) {
+        if (ctx->defer_join) ctx->join_pending = 1;
+        else AT_HIP(hipStreamWaitEvent(stream, ctx->side_ev[1], 0));
+    }
     AT_LAUNCH_CHECK();
     return AT_OK;
 }
@@ -490,6 +496,24 @@ int at_token_histogram_i64(at_ctx* ctx, const int64_t* ids, int64_t n, int k, in
     hipLaunchKernelGGL(histogram_kernel, dim3(blocks), dim3(WG), lds, stream, reinterpret_cast<const long*>(ids), (long)n, k,
                        reinterpret_cast<unsigned long long*>(counts));
     AT_LAUNCH_CHECK();
+    return AT_OK;
+}
+
+// at_centroid_accum_defer(ctx, 1): following at_centroid_accum_f32 calls return without making `stream` wait
+// for the long-list kernel on the context's side stream; at_centroid_accum_join(ctx, stream) inserts that
+// wait (a no-op when nothing is pending) and must precede any use of the sums / counts.
+int at_centroid_accum_defer(at_ctx* ctx, int on) {
+    AT_REQUIRE(ctx, "at_centroid_accum_defer: ctx is null");
+    ctx->defer_join = on ? 1 : 0;
+    return AT_OK;
+}
+
+int at_centroid_accum_join(at_ctx* ctx, void* stream_) {
+    AT_REQUIRE(ctx, "at_centroid_accum_join: ctx is null");
+    if (!ctx->join_pending) return AT_OK;
+    AT_HIP(hipSetDevice(ctx->device));
+    AT_HIP(hipStreamWaitEvent((hipStream_t)stream_, ctx->side_ev[1], 0));
+    ctx->join_pending = 0;
     return AT_OK;
 }
 

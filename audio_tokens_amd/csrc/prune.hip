@@ -339,10 +339,10 @@ int at_visit_order_f32(at_ctx* ctx, const int64_t* ids, const float* dis, int64_
     AT_REQUIRE(n >= 0 && n < (int64_t)UINT32_MAX && k > 0 && k < (1 << 23), "at_visit_order_f32: bad sizes");
     if (n == 0) return AT_OK;
     AT_HIP(hipSetDevice(ctx->device));
-    uint32_t* keys_a = static_cast<uint32_t*>(at_ws(ctx, WS_SORT_KEYS_A, (size_t)n * 4, stream));
-    uint32_t* keys_b = static_cast<uint32_t*>(at_ws(ctx, WS_SORT_KEYS_B, (size_t)n * 4, stream));
-    uint32_t* vals_a = static_cast<uint32_t*>(at_ws(ctx, WS_SORT_VALS_A, (size_t)n * 4, stream));
-    uint32_t* vals_b = static_cast<uint32_t*>(at_ws(ctx, WS_SORT_VALS_B, (size_t)n * 4, stream));
+    uint32_t* keys_a = static_cast<uint32_t*>(at_ws(ctx, WS_VISIT_KEYS_A, (size_t)n * 4, stream));
+    uint32_t* keys_b = static_cast<uint32_t*>(at_ws(ctx, WS_VISIT_KEYS_B, (size_t)n * 4, stream));
+    uint32_t* vals_a = static_cast<uint32_t*>(at_ws(ctx, WS_VISIT_VALS_A, (size_t)n * 4, stream));
+    uint32_t* vals_b = static_cast<uint32_t*>(at_ws(ctx, WS_VISIT_VALS_B, (size_t)n * 4, stream));
     if (!keys_a || !keys_b || !vals_a || !vals_b) return AT_E_NOMEM;
     hipLaunchKernelGGL(visit_keys_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, stream,
                        reinterpret_cast<const long*>(ids), dis, (long)n, k, keys_a, vals_a);
@@ -354,7 +354,7 @@ int at_visit_order_f32(at_ctx* ctx, const int64_t* ids, const float* dis, int64_
     rocprim::double_buffer<uint32_t> vb(vals_a, vals_b);
     size_t tmp_bytes = 0;
     AT_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kb, vb, (size_t)n, 0, bits, stream));
-    void* tmp = at_ws(ctx, WS_SORT_TMP, tmp_bytes, stream);
+    void* tmp = at_ws(ctx, WS_VISIT_TMP, tmp_bytes, stream);
     if (!tmp) return AT_E_NOMEM;
     AT_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, kb, vb, (size_t)n, 0, bits, stream));
     AT_HIP(hipMemcpyAsync(order_out, vb.current(), sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream));

@@ -298,7 +298,7 @@ class Kmeans:
         # relies on is computed once per train() -- it only affects how much gets skipped.
         prune = (self.prune and hasattr(be, "assign_pruned") and d in (64, 128) and k >= 1024
                  and (k + 31) // 32 <= 512 and xs.shape[0] >= 4096)
-        ids = dis = order = None
+        ids = dis = order = vorder = None
         if prune:  # grouping from the initial centroids, kept for the whole train()
             cperm = be.from_host(be.group_rows_kd(be.to_host(cent)))
             gnbr = None
@@ -313,7 +313,8 @@ class Kmeans:
                     gnbr = be.group_neighbours(be.group_means(cent, cperm), 8)
                     ids, dis = be.assign_c2f(xs, cent, cperm, dmin, gnbr)
                 else:
-                    ids, dis = be.assign_pruned(xs, cent, be.visit_order(ids, dis, k), cperm, dmin)
+                    ids, dis = be.assign_pruned(xs, cent, vorder if vorder is not None else be.visit_order(ids, dis, k),
+                                                cperm, dmin)
             elif ids is None:
                 ids, dis = be.assign(xs, cent)
             else:  # same answer, guided by the previous assignment and its member-list order
@@ -321,7 +322,11 @@ class Kmeans:
             tp = lap("assign", tp)
             obj = dist.sum_f64(be.sum_f64(dis))
             if prune:
-                part = be.centroid_accum(xs, ids, k)
+                # the next iteration's visiting order depends on this assignment only: its sort runs behind
+                # the short-list accumulation while the long lists are still being summed on the side stream
+                part = be.centroid_accum(xs, ids, k, defer_join=True)
+                vorder = be.visit_order(ids, dis, k) if it + 1 < self.niter else None
+                be.centroid_accum_join()
             else:
                 part, order = be.centroid_accum(xs, ids, k, want_order=True)
             tp = lap("accumulate", tp)

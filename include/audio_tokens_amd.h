@@ -199,6 +199,13 @@ int at_centroid_accum_f32(at_ctx* ctx, const float* x, int64_t n, int d, const i
  * counts_parts + p*counts_part_stride (strides in floats).  Partials are added in ascending p,
  * then centroids[c] = sum * (1/count) where count > 0 and 0 where the cluster is empty;
  * hassign[c] = count. */
+/* Long member lists are accumulated on a side stream of the context.  By default at_centroid_accum_f32
+ * makes `stream` wait for it before returning; after at_centroid_accum_defer(ctx, 1) that wait is left to
+ * at_centroid_accum_join(ctx, stream), which must precede any use of sums / counts -- work queued on
+ * `stream` in between overlaps the long lists. */
+int at_centroid_accum_defer(at_ctx* ctx, int on);
+int at_centroid_accum_join(at_ctx* ctx, void* stream);
+
 int at_centroid_finalize_f32(at_ctx* ctx, const float* sums_parts, int64_t sums_part_stride,
                              const float* counts_parts, int64_t counts_part_stride, int n_parts,
                              int k, int d, float* centroids, float* hassign, void* stream);
