@@ -30,6 +30,7 @@ enum at_ws_slot {
     WS_VISIT_VALS_A,
     WS_VISIT_VALS_B,
     WS_VISIT_TMP,
+    WS_DMIN_MISC,      // group_min_dist on the matrix cores: max|c|^2 bits
     WS_FILTER_MISC,    // fp16-split filter: max|c|^2 bits, list length; running totals for at_filter_stats
     WS_NSLOTS
 };
@@ -92,5 +93,8 @@ int at_filter_gather_ambiguous(at_ctx* ctx, uint32_t* amb_list, uint32_t* amb_so
 int at_filter_redo_rows(at_ctx* ctx, const float* x, int d, const float* c, int k, const uint32_t* list, int64_t m,
                         const uint32_t* order, const int32_t* cperm, const float* dmin, int ng, const unsigned* misc,
                         const uint32_t* aux, int64_t* ids, float* dist, hipStream_t stream);
+
+int at_group_min_dist_f16(at_ctx* ctx, const float* c, int k, int d, const int32_t* cperm, int ng, float* dmin,
+                          hipStream_t stream);
 
 static inline bool at_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

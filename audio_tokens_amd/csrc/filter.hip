@@ -623,6 +623,89 @@ __global__ void __launch_bounds__(WG) exact_rows_kernel(const float* __restrict_
     }
 }
 
+// dmin[p][g] = a lower bound of min over the members m of group g of |c_p - c_m| (prune.hip uses it in
+// Elkan's test), from the same fp16-split products as the sweep: P(m) + |c_p|^2 - eps <= true squared
+// distance.  One wave = 64 centroids p (two 32-row tiles as the MFMA B operand) x GPW groups.
+constexpr int DMIN_GPW = 16;
+
+template <int D>
+__global__ void __launch_bounds__(64, 2)
+group_min_dist_f16_kernel(const float* __restrict__ C, int k, const unsigned char* __restrict__ img, int ng,
+                          const unsigned* __restrict__ misc, float eps_a, float eps_b, float* __restrict__ dmin) {
+    constexpr int NS = D / 16;
+    constexpr size_t GB = group_bytes(D);
+    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+    const int p0 = blockIdx.x * 64;
+    const int g0 = blockIdx.y * DMIN_GPW;
+    const float cnmax = __uint_as_float(misc[0]);
+    const bool c_bad = !(cnmax < RANGE_SQ);
+
+    half8 xh[2][NS], xl[2][NS];
+    float cnp[2], eps[2];
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        int p = p0 + 32 * b + j;
+        if (p >= k) p = k - 1;
+        const f32x4* row = reinterpret_cast<const f32x4*>(C + (size_t)p * D);
+        float part = 0.0f;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const f32x4 u = row[4 * s + 2 * h], v = row[4 * s + 2 * h + 1];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                part = __builtin_fmaf(u[e], u[e], part);
+                const _Float16 hu = (_Float16)u[e];
+                xh[b][s][e] = hu;
+                xl[b][s][e] = (_Float16)(u[e] - (float)hu);
+                part = __builtin_fmaf(v[e], v[e], part);
+                const _Float16 hv = (_Float16)v[e];
+                xh[b][s][4 + e] = hv;
+                xl[b][s][4 + e] = (_Float16)(v[e] - (float)hv);
+            }
+        }
+        cnp[b] = part + __shfl_xor(part, 32);
+        eps[b] = __builtin_fmaf(eps_a, cnp[b] * 1.001f + cnmax, eps_b);
+    }
+    for (int g = g0; g < g0 + DMIN_GPW && g < ng; g++) {
+        const unsigned char* base = img + (size_t)g * GB;
+        const half8* fh = reinterpret_cast<const half8*>(base);
+        const half8* fl = reinterpret_cast<const half8*>(base + lo_off(D));
+        half8 ah[NS], al[NS];
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            ah[s] = fh[s * 64 + lane];
+            al[s] = fl[s * 64 + lane];
+        }
+        f32x4 cn[4];
+        const float* cnq = reinterpret_cast<const float*>(base + misc_off(D));
+#pragma unroll
+        for (int q = 0; q < 4; q++) cn[q] = *reinterpret_cast<const f32x4*>(cnq + 8 * q + 4 * h);
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            f32x16 a = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], xh[b][s], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xl[b][s], a, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < NS; s++) a = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[b][s], a, 0, 0, 0);
+            float P[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) P[r] = __builtin_fmaf(-2.0f, a[r], cn[r >> 2][r & 3]);
+            float m = min16(P);
+            m = __builtin_fminf(m, __shfl_xor(m, 32));
+            const int p = p0 + 32 * b + j;
+            if (h == 0 && p < k) {
+                // true squared distance >= P + |c_p|^2 - eps; padding slots carry |c|^2 = +inf
+                float lb = m == __builtin_inff() ? m : __builtin_sqrtf(__builtin_fmaxf((m + cnp[b]) - eps[b], 0.0f)) * (1.0f - 1e-6f);
+                if (c_bad || !(lb == lb)) lb = 0.0f;   // outside the fp16 range / non-finite: no pruning
+                dmin[(size_t)p * ng + g] = lb;
+            }
+        }
+    }
+}
+
 void filter_tau(int d, float* tau_a, float* tau_b) {
     const double u = std::ldexp(1.0, -24);
     const double q = std::sqrt((double)d) * std::ldexp(1.0, -25);
@@ -757,6 +840,33 @@ int at_filter_redo_rows(at_ctx* ctx, const float* x, int d, const float* c, int 
     else
         hipLaunchKernelGGL(exact_rows_kernel<128>, dim3((unsigned)m), dim3(WG), 0, stream, x, c, k, list, order, cperm,
                            dmin, ng, misc, aux, reinterpret_cast<long*>(ids), dist);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}
+
+// at_group_min_dist_f32 through the matrix cores (d = 64 / 128): builds the fp16 image of the grouped
+// centroids (the sweep rebuilds it anyway) and bounds every centroid-to-group distance from below.
+int at_group_min_dist_f16(at_ctx* ctx, const float* c, int k, int d, const int32_t* cperm, int ng, float* dmin,
+                          hipStream_t stream) {
+    unsigned char* img = static_cast<unsigned char*>(at_ws(ctx, WS_CENT_IMG16, group_bytes(d) * (size_t)ng, stream));
+    unsigned* misc = static_cast<unsigned*>(at_ws(ctx, WS_DMIN_MISC, 256, stream));
+    if (!img || !misc) return AT_E_NOMEM;
+    hipLaunchKernelGGL(prep_centroids_f16_kernel, dim3(ng), dim3(WG), 0, stream, c, k, d, cperm, img);
+    AT_LAUNCH_CHECK();
+    AT_HIP(hipMemsetAsync(misc, 0, sizeof(unsigned), stream));
+    hipLaunchKernelGGL(max_sqnorm_bits_kernel, dim3((k + WG - 1) / WG), dim3(WG), 0, stream, c, k, d, misc);
+    AT_LAUNCH_CHECK();
+    // eps of the filter's budget (header of this file) without the contract's delta: tau = 2 delta + 2 eps
+    float ta = 0.0f, tb = 0.0f;
+    filter_tau(d, &ta, &tb);
+    const double u = std::ldexp(1.0, -24);
+    const float eps_a = (float)(0.5 * ((double)ta - 2.0 * (2.0 * d + 8.0) * u * 1.01) * 1.001);
+    const float eps_b = 0.5f * tb * 1.001f;
+    const dim3 grid((unsigned)((k + 63) / 64), (unsigned)((ng + DMIN_GPW - 1) / DMIN_GPW));
+    if (d == 64)
+        hipLaunchKernelGGL(group_min_dist_f16_kernel<64>, grid, dim3(64), 0, stream, c, k, img, ng, misc, eps_a, eps_b, dmin);
+    else
+        hipLaunchKernelGGL(group_min_dist_f16_kernel<128>, grid, dim3(64), 0, stream, c, k, img, ng, misc, eps_a, eps_b, dmin);
     AT_LAUNCH_CHECK();
     return AT_OK;
 }

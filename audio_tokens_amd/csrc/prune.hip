@@ -17,6 +17,7 @@
 //   group_min_dist_kernel : dmin[p][g] = lower bound of min_{c in group g} |c - c_p|
 //   visit order           : stable radix sort of (p << 8 | quantised distance, row)
 //   prune_mask_kernel     : per row bd; per 32-row tile one bit per group ("some row needs it")
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -297,6 +298,8 @@ int at_group_min_dist_f32(at_ctx* ctx, const float* c, int k, int d, const int32
     AT_REQUIRE(ctx && c && cperm && dmin && k > 0 && d > 0 && ng > 0, "at_group_min_dist_f32: bad arguments");
     AT_REQUIRE((d == 64 || d == 128) && at_aligned16(c), "at_group_min_dist_f32: d must be 64 or 128");
     AT_HIP(hipSetDevice(ctx->device));
+    const char* dv = std::getenv("AT_DMIN_KERNEL");  // A/B aid: 0 = the fp32 vector-ALU kernel below
+    if (!(dv && std::atoi(dv) == 0)) return at_group_min_dist_f16(ctx, c, k, d, cperm, ng, dmin, stream);
     const dim3 grid(ng, (k + WG - 1) / WG);
     if (d == 64)
         hipLaunchKernelGGL(group_min_dist_kernel<64>, grid, dim3(WG), 0, stream, c, k, cperm, ng, dmin);
