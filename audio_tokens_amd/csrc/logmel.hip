@@ -34,6 +34,8 @@ struct LogmelParams {
     const float* wave;
     long n_clips, L, wave_stride;
     int hop, T, n_mels, fpb;
+    long n_blocks;          // (clip, block of fpb frames) pairs, walked by persistent workgroups
+    int blocks_per_clip;
     const float* tabs;      // TAB_FLOATS floats: window, W256 twiddles, W512 twiddles
     const int* fb_start;    // [n_mels]
     const int* fb_len;      // [n_mels]
@@ -53,13 +55,13 @@ __global__ void __launch_bounds__(WG, 2) logmel_kernel(LogmelParams p) {
     const int nsamp = (p.fpb - 1) * p.hop + NFFT;
     const int opitch = p.n_mels + 1;
 
-    float* tabs = sm;                              // TAB_FLOATS
-    float* samp = tabs + TAB_FLOATS;               // nsamp (rounded up to 4)
+    float* win = sm;                               // NFFT window values
+    float* tw512 = win + NFFT;                     // 256 x (cos, -sin)
+    float* samp = tw512 + NFFT;                    // nsamp (rounded up to 4)
     float* work = samp + ((nsamp + 3) & ~3);       // 16 frames x FRAME_LDS_FLOATS
     float* ostage = work + 16 * FRAME_LDS_FLOATS;  // fpb x opitch  (+ fpb denominators)
     // filterbank tables behind the staging area, 16-byte aligned: start4 | quads | off | padded weights
-    int* fbi = reinterpret_cast<int*>(sm + ((TAB_FLOATS + ((nsamp + 3) & ~3) + 16 * FRAME_LDS_FLOATS +
-                                             p.fpb * opitch + p.fpb + 3) & ~3));
+    int* fbi = reinterpret_cast<int*>(sm + ((2 * NFFT + ((nsamp + 3) & ~3) + 16 * FRAME_LDS_FLOATS + p.fpb * opitch + p.fpb + 3) & ~3));
     const int* fb_start = p.fb_start;
     const int* fb_len = p.fb_len;
     const int* fb_off = p.fb_off;
@@ -72,75 +74,87 @@ __global__ void __launch_bounds__(WG, 2) logmel_kernel(LogmelParams p) {
         fb_off = fbi + 2 * p.n_mels;
         fb_wts = reinterpret_cast<const float*>(fbi + nint);
     }
-
-    const long clip = blockIdx.y;
-    const int t0 = blockIdx.x * p.fpb;
-    const float* w = p.wave + clip * p.wave_stride;
-
-    for (int i = tid; i < TAB_FLOATS; i += WG) tabs[i] = p.tabs[i];
-    {
-        const long s0 = (long)t0 * p.hop - NFFT / 2;
-        for (int i = tid; i < nsamp; i += WG) {
-            long q = s0 + i;
-            if (q < 0) q = -q;                      // reflect, no edge repeat
-            if (q >= p.L) q = 2 * (p.L - 1) - q;
-            if (q < 0) q = 0;                       // only reachable for frames past T (never stored)
-            if (q >= p.L) q = p.L - 1;
-            samp[i] = w[q];
-        }
+    // A lane's twiddles do not depend on the frame: they live in registers for the whole (persistent)
+    // workgroup instead of being read from LDS once per frame (the window stays in LDS: the register file
+    // does not hold more beside two 16-point FFTs; window and W512 stay in LDS).
+    cpx twr[16];
+#pragma unroll
+    for (int k1 = 0; k1 < 16; k1++)
+        twr[k1] = {p.tabs[TAB_TW256 + 2 * (k1 * 16 + l16)], p.tabs[TAB_TW256 + 2 * (k1 * 16 + l16) + 1]};
+    for (int i = tid; i < NFFT; i += WG) {
+        win[i] = p.tabs[TAB_WIN + i];
+        tw512[i] = p.tabs[TAB_TW512 + i];
     }
-    __syncthreads();
 
     float* mybuf = work + (wave * 4 + grp) * FRAME_LDS_FLOATS;
     const int n_mel_iter = (p.n_mels + 15) >> 4;
-    for (int pass = 0; pass * 16 < p.fpb; pass++) {
-        const int f = pass * 16 + wave * 4 + grp;   // frame within the workgroup
-        // every DS access below stays inside this frame's 16 lanes' private tile; a wavefront's
-        // LDS instructions execute in order, so no barrier is needed between the phases
-        phase1(l16, samp + f * p.hop, tabs + TAB_WIN, tabs + TAB_TW256, mybuf);
-        cpx z[16];
-        phase2(l16, mybuf, z);
-        phase3_publish(l16, z, mybuf);
-        float pw[16], p256 = 0.0f;
-        phase3_power(l16, z, mybuf, tabs + TAB_TW512, pw, p256);
-#pragma unroll
-        for (int e = 0; e < 16; e++) mybuf[l16 + 16 * e] = pw[e];
-        if (l16 < 4) mybuf[256 + l16] = l16 == 0 ? p256 : 0.0f;  // bins 257..259 pad the last quad
-        for (int i = 0; i < n_mel_iter; i++) {
-            const int m = l16 + 16 * i;
-            if (m < p.n_mels) {
-                const float s = p.fb_quads ? mel_band(mybuf, fb_start[m], fb_len[m], fb_wts + fb_off[m])
-                                           : mel_band_plain(mybuf, fb_start[m], fb_len[m], fb_wts + fb_off[m]);
-                // clamp(x, 1e-10) then 10*log10: a clamped bin is exactly -100 dB (what a correctly
-                // rounded log10 of 1e-10f gives; the device log10f is 1 ulp off there)
-                ostage[f * opitch + m] = s > 1e-10f ? 10.0f * log10f(s) : -100.0f;
+    for (long blk = blockIdx.x; blk < p.n_blocks; blk += gridDim.x) {
+        const long clip = blk / p.blocks_per_clip;
+        const int t0 = (int)(blk - clip * p.blocks_per_clip) * p.fpb;
+        const float* w = p.wave + clip * p.wave_stride;
+        {
+            const long s0 = (long)t0 * p.hop - NFFT / 2;
+            for (int i = tid; i < nsamp; i += WG) {
+                long q = s0 + i;
+                if (q < 0) q = -q;                      // reflect, no edge repeat
+                if (q >= p.L) q = 2 * (p.L - 1) - q;
+                if (q < 0) q = 0;                       // only reachable for frames past T (never stored)
+                if (q >= p.L) q = p.L - 1;
+                samp[i] = w[q];
             }
         }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    const int nf = min(p.fpb, p.T - t0);  // frames of this workgroup that exist
-    if (p.frame_major) {
-        float* den = ostage + p.fpb * opitch;
-        if (p.fuse_l2norm) {
-            for (int f = tid; f < nf; f += WG) den[f] = l2n::row_denominator(ostage + f * opitch, p.n_mels, 1);
-            __syncthreads();
+        for (int pass = 0; pass * 16 < p.fpb; pass++) {
+            const int f = pass * 16 + wave * 4 + grp;   // frame within the workgroup
+            // every DS access below stays inside this frame's 16 lanes' private tile; a wavefront's
+            // LDS instructions execute in order, so no barrier is needed between the phases
+            phase1_w(l16, samp + f * p.hop, win, twr, mybuf);
+            cpx z[16];
+            phase2(l16, mybuf, z);
+            phase3_publish(l16, z, mybuf);
+            float pw[16], p256 = 0.0f;
+            phase3_power(l16, z, mybuf, tw512, pw, p256);
+#pragma unroll
+            for (int e = 0; e < 16; e++) mybuf[l16 + 16 * e] = pw[e];
+            if (l16 < 4) mybuf[256 + l16] = l16 == 0 ? p256 : 0.0f;  // bins 257..259 pad the last quad
+            for (int i = 0; i < n_mel_iter; i++) {
+                const int m = l16 + 16 * i;
+                if (m < p.n_mels) {
+                    const float s = p.fb_quads ? mel_band(mybuf, fb_start[m], fb_len[m], fb_wts + fb_off[m])
+                                               : mel_band_plain(mybuf, fb_start[m], fb_len[m], fb_wts + fb_off[m]);
+                    // clamp(x, 1e-10) then 10*log10: a clamped bin is exactly -100 dB (what a correctly
+                    // rounded log10 of 1e-10f gives; the device log10f is 1 ulp off there)
+                    ostage[f * opitch + m] = s > 1e-10f ? 10.0f * log10f(s) : -100.0f;
+                }
+            }
         }
-        float* dst = p.out + ((long)clip * p.T + t0) * p.n_mels;
-        const int total = nf * p.n_mels;
-        for (int e = tid; e < total; e += WG) {
-            const int f = e / p.n_mels, m = e - f * p.n_mels;
-            float v = ostage[f * opitch + m];
-            if (p.fuse_l2norm) v = l2n::divide(v, den[f]);
-            dst[e] = v;
+        __syncthreads();
+
+        const int nf = min(p.fpb, p.T - t0);  // frames of this block that exist
+        if (p.frame_major) {
+            float* den = ostage + p.fpb * opitch;
+            if (p.fuse_l2norm) {
+                for (int f = tid; f < nf; f += WG) den[f] = l2n::row_denominator(ostage + f * opitch, p.n_mels, 1);
+                __syncthreads();
+            }
+            float* dst = p.out + ((long)clip * p.T + t0) * p.n_mels;
+            const int total = nf * p.n_mels;
+            for (int e = tid; e < total; e += WG) {
+                const int f = e / p.n_mels, m = e - f * p.n_mels;
+                float v = ostage[f * opitch + m];
+                if (p.fuse_l2norm) v = l2n::divide(v, den[f]);
+                dst[e] = v;
+            }
+        } else {
+            float* dst = p.out + (long)clip * p.n_mels * p.T + t0;
+            const int total = p.n_mels * p.fpb;
+            for (int e = tid; e < total; e += WG) {
+                const int m = e / p.fpb, f = e - m * p.fpb;
+                if (f < nf) dst[(long)m * p.T + f] = ostage[f * opitch + m];
+            }
         }
-    } else {
-        float* dst = p.out + (long)clip * p.n_mels * p.T + t0;
-        const int total = p.n_mels * p.fpb;
-        for (int e = tid; e < total; e += WG) {
-            const int m = e / p.fpb, f = e - m * p.fpb;
-            if (f < nf) dst[(long)m * p.T + f] = ostage[f * opitch + m];
-        }
+        __syncthreads();  // the staging areas are rewritten by the next block
     }
 }
 
@@ -148,7 +162,7 @@ __global__ void __launch_bounds__(WG, 2) logmel_kernel(LogmelParams p) {
 // LDS bytes of one workgroup of `fpb` frames (kernel layout), with `fb_ints` words of filterbank tables
 size_t lds_bytes(int fpb, int hop, int n_mels, size_t fb_ints) {
     const int nsamp = (fpb - 1) * hop + NFFT;
-    return sizeof(float) * ((size_t)TAB_FLOATS + ((nsamp + 3) & ~3) + 16 * FRAME_LDS_FLOATS + (size_t)fpb * (n_mels + 1) + fpb) +
+    return sizeof(float) * ((size_t)2 * NFFT + ((nsamp + 3) & ~3) + 16 * FRAME_LDS_FLOATS + (size_t)fpb * (n_mels + 1) + fpb) +
            fb_ints * 4 + 16;
 }
 constexpr size_t LDS_TWO_PER_CU = 80 * 1024;  // two workgroups of this size share a CU
@@ -281,15 +295,16 @@ extern "C" int at_logmel_f32(at_ctx* ctx, const float* wave, int64_t n_clips, in
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
-    const unsigned gx = (unsigned)((T + p.fpb - 1) / p.fpb);
-    // gridDim.y is limited to 65535: sweep the clips in slabs
-    for (int64_t c0 = 0; c0 < n_clips; c0 += 65535) {
-        const unsigned gy = (unsigned)((n_clips - c0) < 65535 ? (n_clips - c0) : 65535);
-        LogmelParams q = p;
-        q.wave = wave + c0 * wave_stride;
-        q.out = out + c0 * (int64_t)n_mels * T;
-        hipLaunchKernelGGL(logmel_kernel, dim3(gx, gy), dim3(WG), lds, stream, q);
-        AT_LAUNCH_CHECK();
-    }
+    p.blocks_per_clip = (int)((T + p.fpb - 1) / p.fpb);
+    p.n_blocks = (long)p.blocks_per_clip * n_clips;
+    // persistent workgroups: two per CU (what the LDS footprint allows), each walking a strided share
+    // of the blocks with its window / twiddle tables in registers
+    int cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    long grid = 2L * cus;
+    if (grid > p.n_blocks) grid = p.n_blocks;
+    hipLaunchKernelGGL(logmel_kernel, dim3((unsigned)grid), dim3(WG), lds, stream, p);
+    AT_LAUNCH_CHECK();
     return AT_OK;
 }

@@ -82,7 +82,25 @@ AT_HD void dft16(cpx (&v)[16]) {
 //   frame : the 512 samples of this frame (already reflect-padded), win : 512 window values,
 //   tw256 : 16 x 16 x (cos, -sin): entry [k1][m2] = W256^(m2*k1), so the 16 lanes of a frame read
 //           consecutive words; ebuf : FRAME_LDS_FLOATS floats.
-AT_HD void phase1(int l, const float* frame, const float* win, const float* tw256, float* ebuf) {
+// (register form: winr[2*m1 + {0,1}] = win[32*m1 + 2*l + {0,1}], twr[k1] = tw256 entry [k1][l]; a lane's
+// table entries do not depend on the frame, so a kernel that walks many frames loads them once)
+AT_HD void phase1_r(int l, const float* frame, const float (&winr)[32], const cpx (&twr)[16], float* ebuf) {
+    cpx v[16];
+#pragma unroll
+    for (int m1 = 0; m1 < 16; m1++) {
+        const int s = 32 * m1 + 2 * l;
+        v[m1] = {frame[s] * winr[2 * m1], frame[s + 1] * winr[2 * m1 + 1]};  // torch: frames * window, fp32
+    }
+    dft16(v);  // v[k1]
+#pragma unroll
+    for (int k1 = 0; k1 < 16; k1++) {
+        const cpx y = k1 == 0 ? v[0] : cmul(v[k1], twr[k1]);
+        ebuf[2 * (k1 * EPITCH + l)] = y.re;
+        ebuf[2 * (k1 * EPITCH + l) + 1] = y.im;
+    }
+}
+// (window from memory, twiddles in registers)
+AT_HD void phase1_w(int l, const float* frame, const float* win, const cpx (&twr)[16], float* ebuf) {
     cpx v[16];
 #pragma unroll
     for (int m1 = 0; m1 < 16; m1++) {
@@ -92,12 +110,25 @@ AT_HD void phase1(int l, const float* frame, const float* win, const float* tw25
     dft16(v);  // v[k1]
 #pragma unroll
     for (int k1 = 0; k1 < 16; k1++) {
-        const int j = k1 * 16 + l;
-        const cpx w = {tw256[2 * j], tw256[2 * j + 1]};
-        const cpx y = k1 == 0 ? v[0] : cmul(v[k1], w);
+        const cpx y = k1 == 0 ? v[0] : cmul(v[k1], twr[k1]);
         ebuf[2 * (k1 * EPITCH + l)] = y.re;
         ebuf[2 * (k1 * EPITCH + l) + 1] = y.im;
     }
+}
+AT_HD void load_phase1_tables(int l, const float* win, const float* tw256, float (&winr)[32], cpx (&twr)[16]) {
+#pragma unroll
+    for (int m1 = 0; m1 < 16; m1++) {
+        winr[2 * m1] = win[32 * m1 + 2 * l];
+        winr[2 * m1 + 1] = win[32 * m1 + 2 * l + 1];
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 16; k1++) twr[k1] = {tw256[2 * (k1 * 16 + l)], tw256[2 * (k1 * 16 + l) + 1]};
+}
+AT_HD void phase1(int l, const float* frame, const float* win, const float* tw256, float* ebuf) {
+    float winr[32];
+    cpx twr[16];
+    load_phase1_tables(l, win, tw256, winr, twr);
+    phase1_r(l, frame, winr, twr, ebuf);
 }
 
 // Phase 2, lane l = k1: row FFT.  On return z[k2] = Z[k1 + 16*k2].
@@ -119,8 +150,8 @@ AT_HD void phase3_publish(int l, const cpx (&z)[16], float* zbuf) {
 
 // Phase 3b, lane l: power of bins k = l + 16*e (e = 0..15); lane 0 also returns bin 256 in p256.
 //   tw512 : 256 x (cos, -sin) of 2*pi*k/512.
-AT_HD void phase3_power(int l, const cpx (&z)[16], const float* zbuf, const float* tw512,
-                        float (&p)[16], float& p256) {
+AT_HD void phase3_power_r(int l, const cpx (&z)[16], const float* zbuf, const cpx (&t5)[16], float (&p)[16],
+                          float& p256) {
 #pragma unroll
     for (int e = 0; e < 16; e++) {
         const int k = l + 16 * e;
@@ -130,14 +161,23 @@ AT_HD void phase3_power(int l, const cpx (&z)[16], const float* zbuf, const floa
         const cpx ev = {0.5f * (a.re + b.re), 0.5f * (a.im + b.im)};
         const cpx df = {0.5f * (a.re - b.re), 0.5f * (a.im - b.im)};
         const cpx od = {df.im, -df.re};               // -i * df
-        const cpx w = {tw512[2 * k], tw512[2 * k + 1]};
-        const cpx x = cadd(ev, cmul(od, w));
+        const cpx x = cadd(ev, cmul(od, t5[e]));
         p[e] = __builtin_fmaf(x.re, x.re, x.im * x.im);
         if (k == 0) {
             const float n = a.re - a.im;              // X[256] = Re Z0 - Im Z0 (purely real)
             p256 = n * n;
         }
     }
+}
+AT_HD void load_phase3_table(int l, const float* tw512, cpx (&t5)[16]) {
+#pragma unroll
+    for (int e = 0; e < 16; e++) t5[e] = {tw512[2 * (l + 16 * e)], tw512[2 * (l + 16 * e) + 1]};
+}
+AT_HD void phase3_power(int l, const cpx (&z)[16], const float* zbuf, const float* tw512,
+                        float (&p)[16], float& p256) {
+    cpx t5[16];
+    load_phase3_table(l, tw512, t5);
+    phase3_power_r(l, z, zbuf, t5, p, p256);
 }
 
 // Phase 4: one mel filter = banded dot product over the power spectrum.  The band is stored padded
