@@ -348,16 +348,18 @@ class HipBackend(HostHelpers):
         ids = self.empty((n,), torch.int64)
         dist = self.empty((n,), torch.float32) if want_dist else None
         rec = self.assign_trace
+        # exact filtered calls do their pre-pass (guess distances + group masks) inside the sweep kernel
+        fused = use_filter and mode == 0 and os.environ.get("AT_FILTER_FUSED", "1") != "0"
         with torch.cuda.device(self.device):
-            # pre-pass (bound + masks) first, so that the events below bracket the sweep kernel only
-            _lib.check(self.lib.at_prune_mask_f32(self.ctx.handle, _ptr(x), n, d, _ptr(c), k, _ptr(order),
-                                                  _ptr(hint_sorted), ng, _ptr(dmin), mode, self._stream()))
+            if not fused:  # pre-pass first, so that the events below bracket the sweep kernel only
+                _lib.check(self.lib.at_prune_mask_f32(self.ctx.handle, _ptr(x), n, d, _ptr(c), k, _ptr(order),
+                                                      _ptr(hint_sorted), ng, _ptr(dmin), mode, self._stream()))
             if rec is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(torch.cuda.current_stream(self.device))
             _lib.check(self.lib.at_assign_pruned_f32(self.ctx.handle, _ptr(x), n, d, _ptr(c), k, _ptr(order),
                                                      _ptr(hint_sorted), _ptr(cperm), ng, _ptr(dmin),
-                                                     mode | (2 if use_filter else 0), 1, _ptr(ids),
+                                                     mode | (2 if use_filter else 0), 0 if fused else 1, _ptr(ids),
                                                      _ptr(dist), self._stream()))
         if rec is not None:
             e1.record(torch.cuda.current_stream(self.device))

@@ -1258,7 +1258,10 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
     // image: one tile per group (NA = 1): 32 rows, then |c|^2 at [0,32) and indices at [128,160)
     hipLaunchKernelGGL(prep_centroids_perm_kernel, dim3(ng), dim3(WG), 0, stream, c, k, D, cperm, kp, 1, img);
     AT_LAUNCH_CHECK();
-    if (!prepass_done) {
+    // exact filtered calls without a pre-pass done by the caller: the sweep does it in its prologue
+    const char* fz = std::getenv("AT_FILTER_FUSED");  // A/B aid: 0 = separate pre-pass kernel
+    const bool fuse = filter && mode == 0 && !prepass_done && !(fz && std::atoi(fz) == 0);
+    if (!prepass_done && !fuse) {
         int rc = at_prune_prepass(ctx, x, n, D, c, k, order, hint_sorted, dmin, ng, bd, mask, ngw, mode, stream);
         if (rc) return rc;
     }
@@ -1276,7 +1279,8 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
         if (!misc || !list) return AT_E_NOMEM;
         uint32_t* aux = list + 4 * ((size_t)n + 64);
         int rc = at_filter_sweep(ctx, x, n, D, c, k, order, cperm, ng, bd, mask, ngw, mode == 0 ? 1 : 0, ids, misc, list,
-                                 aux, nullptr, stream);
+                                 aux, nullptr, fuse ? hint_sorted : nullptr, fuse ? dmin : nullptr, fuse ? bd : nullptr,
+                                 stream);
         if (rc) return rc;
         if (dist) {
             rc = mode == 0 ? at_exact_dist_rows(ctx, x, n, D, c, k, ids, dist, order, hint_sorted, bd, stream)
@@ -1411,7 +1415,7 @@ extern "C" int at_filter_probe_f32(at_ctx* ctx, const float* x, int64_t n, int d
     int rc = at_prune_prepass(ctx, x, n, d, c, k, order, hint_sorted, dmin, ng, bd, mask, ngw, 0, stream);
     if (rc) return rc;
     rc = at_filter_sweep(ctx, x, n, d, c, k, order, cperm, ng, bd, mask, ngw, 1, ids, misc, list,
-                         list + 4 * ((size_t)n + 64), approx, stream);
+                         list + 4 * ((size_t)n + 64), approx, nullptr, nullptr, nullptr, stream);
     if (rc) return rc;
     unsigned cnt = 0;
     AT_HIP(hipMemcpyAsync(&cnt, misc + 1, sizeof cnt, hipMemcpyDeviceToHost, stream));

@@ -117,14 +117,25 @@ __device__ __forceinline__ float min16(const float (&p)[16]) {
     return __builtin_fminf(__builtin_fminf(a, b), __builtin_fminf(c, d));
 }
 
-template <int D, int NB, bool GUESS>
+// What the fused pre-pass needs (FUSED instantiation): the guesses in visiting order, the raw
+// centroids, the centroid-to-group bounds, and where to leave the exact guess distances / statistics.
+struct FusedPrepass {
+    const uint32_t* hint_sorted;
+    const float* C;
+    const float* dmin;
+    float* bd_out;
+    unsigned long long* stats;
+    int k;
+};
+
+template <int D, int NB, bool GUESS, bool FUSED>
 __global__ void __launch_bounds__(64, 2)
 assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char* __restrict__ img, int ng,
                         const uint32_t* __restrict__ order, const float* __restrict__ bd_in,
                         const uint32_t* __restrict__ mask, int ngw, unsigned* __restrict__ misc, float tau_a,
                         float tau_b, float rho_a, float rho_b, int screen, int collect, long* __restrict__ ids,
                         uint32_t* __restrict__ amb_list, uint32_t* __restrict__ amb_aux,
-                        float* __restrict__ approx_out) {
+                        float* __restrict__ approx_out, FusedPrepass fp) {
     static_assert(NB == 2 || NB == 4, "tiles are processed in pairs");
     constexpr int NS = D / 16;
     constexpr size_t GB = group_bytes(D);
@@ -146,6 +157,8 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
     unsigned i1[NB], i2[NB];
     bool bad[NB];
     unsigned rowid[NB];
+    float mtau[FUSED ? NB : 1];      // fused pre-pass: the row's Elkan radius (2R) / its guess
+    uint32_t hintp[FUSED ? NB : 1];
 #pragma unroll
     for (int b = 0; b < NB; b++) {
         long pos = pos0 + 32 * b + j;
@@ -154,9 +167,68 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
         rowid[b] = r;
         const f32x4* p = reinterpret_cast<const f32x4*>(X + (size_t)r * D);
         float part = 0.0f;
+        f32x4 xu[NS], xv[NS];
 #pragma unroll
         for (int s = 0; s < NS; s++) {
-            const f32x4 u = p[4 * s + 2 * h], v = p[4 * s + 2 * h + 1];
+            xu[s] = p[4 * s + 2 * h];
+            xv[s] = p[4 * s + 2 * h + 1];
+        }
+        float bd = __builtin_inff();
+        float nrm;
+        if constexpr (FUSED) {
+            // The pre-pass in place (prune.hip prune_mask_kernel): the exact distance to the guess is the
+            // contract's three ascending fmaf chains.  The row's features sit in 8-wide chunks on lanes
+            // j (even chunks) and j+32 (odd chunks), so the chain state hops between the two lanes:
+            // both compute every step on their own chunk, the owner's result is the one that is kept.
+            const uint32_t g = fp.hint_sorted[pos];
+            const bool has = g < (uint32_t)fp.k;
+            hintp[b] = has ? g : NONE;
+            const f32x4* pc = reinterpret_cast<const f32x4*>(fp.C + (size_t)(has ? g : 0u) * D);
+            f32x4 cu[NS], cv[NS];
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                cu[s] = pc[4 * s + 2 * h];
+                cv[s] = pc[4 * s + 2 * h + 1];
+            }
+            float xn = 0.0f, cn = 0.0f, ip = 0.0f;
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+#pragma unroll
+                for (int owner = 0; owner < 2; owner++) {
+                    float a = xn, c2 = cn, d2 = ip;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        a = __builtin_fmaf(xu[s][e], xu[s][e], a);
+                        c2 = __builtin_fmaf(cu[s][e], cu[s][e], c2);
+                        d2 = __builtin_fmaf(cu[s][e], xu[s][e], d2);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        a = __builtin_fmaf(xv[s][e], xv[s][e], a);
+                        c2 = __builtin_fmaf(cv[s][e], cv[s][e], c2);
+                        d2 = __builtin_fmaf(cv[s][e], xv[s][e], d2);
+                    }
+                    const float oa = __shfl_xor(a, 32), oc = __shfl_xor(c2, 32), od = __shfl_xor(d2, 32);
+                    const bool mine = h == owner;
+                    xn = mine ? a : oa;
+                    cn = mine ? c2 : oc;
+                    ip = mine ? d2 : od;
+                }
+            }
+            nrm = xn;
+            // exactly the value the fp32 sweep would produce for (x, c_p)
+            const float dh = __builtin_fmaxf(__builtin_fmaf(-2.0f, ip, xn + cn), 0.0f);
+            bd = has ? dh : __builtin_inff();
+            if (h == 0 && pos0 + 32 * b + j < n) fp.bd_out[pos] = bd;
+            const float delta = (2.0f * D + 8.0f) * 5.9604645e-8f * (xn + cnmax) * 1.01f;
+            // rows without a guess need every group; positions past n need none
+            mtau[b] = pos0 + 32 * b + j >= n ? -1.0f
+                                             : (has ? 2.0f * sqrtf(dh + delta) * (1.0f + 4.0f * 5.9604645e-8f) + 1e-30f
+                                                    : __builtin_inff());
+        }
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const f32x4 u = xu[s], v = xv[s];
             half8 xlo;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
@@ -174,11 +246,13 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
             }
             xl_lds[b][s][lane] = xlo;
         }
-        const float nrm = part + __shfl_xor(part, 32);
+        if constexpr (!FUSED) {
+            nrm = part + __shfl_xor(part, 32);
+            bd = bd_in[pos];
+        }
         tau[b] = __builtin_fmaf(tau_a, nrm * 1.001f + cnmax, tau_b);
         rho[b] = screen ? __builtin_fmaf(rho_a, nrm * 1.001f + cnmax, rho_b) : __builtin_inff();
         bad[b] = c_bad || !(nrm < RANGE_SQ);
-        const float bd = bd_in[pos];
         // candidates above the cap can neither be the arg-min nor within tau of it: the guess itself
         // (always admitted by the masks) has P <= bd - |x|^2 + eps
         const float cap = bd < __builtin_inff() ? (bd - nrm) + 3.0f * tau[b] : __builtin_inff();
@@ -201,7 +275,67 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
 
     // needed groups of this wave, compacted: entry = group | (tile bits << 9)
     int cnt = 0;
-    {
+    if constexpr (FUSED) {
+        // per tile (its 32 rows are on lanes 0..31 and again on 32..63): a group is needed iff
+        // dmin[p][g] <= the largest radius of some run of equal guesses p (prune_mask_kernel's test,
+        // lanes standing for groups, one coalesced read of the run's dmin row per 64 groups)
+        unsigned long long need[NB][8];
+        int needed_total = 0;
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+#pragma unroll
+            for (int it = 0; it < 8; it++) need[b][it] = 0ull;
+            const bool live = mtau[b] >= 0.0f;            // position < n
+            const bool nohint = live && hintp[b] == NONE;
+            if (__builtin_amdgcn_ballot_w64(nohint) != 0) {
+#pragma unroll
+                for (int it = 0; it < 8; it++) need[b][it] = ~0ull;
+            } else {
+                unsigned long long todo = __builtin_amdgcn_ballot_w64(live) & 0xffffffffull;
+                while (todo != 0) {
+                    const int leader = __builtin_ctzll(todo);
+                    const uint32_t pl = (uint32_t)__builtin_amdgcn_readlane((int)hintp[b], leader);
+                    const bool in_run = live && hintp[b] == pl;
+                    todo &= ~__builtin_amdgcn_ballot_w64(in_run);
+                    float t = in_run ? mtau[b] : -1.0f;
+#pragma unroll
+                    for (int off = 16; off > 0; off >>= 1) t = __builtin_fmaxf(t, __shfl_xor(t, off));
+                    const float* drow = fp.dmin + (size_t)pl * ng;
+#pragma unroll
+                    for (int it = 0; it < 8; it++) {
+                        const int g = 64 * it + lane;
+                        if (64 * it < ng) need[b][it] |= __builtin_amdgcn_ballot_w64(g < ng && drow[g] <= t);
+                    }
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                if (64 * it >= ng) break;
+                if (ng - 64 * it < 64) need[b][it] &= (1ull << (ng - 64 * it)) - 1ull;
+                if (pos0 + 32 * b < n) needed_total += __builtin_popcountll(need[b][it]);
+                else need[b][it] = 0ull;
+            }
+        }
+        if (lane == 0) {  // statistics only (256 slots to keep the atomics off one address)
+            unsigned long long* slot = fp.stats + 2 * (blockIdx.x & 255);
+            int tiles_here = 0;
+#pragma unroll
+            for (int b = 0; b < NB; b++) tiles_here += pos0 + 32 * b < n;
+            atomicAdd(&slot[0], (unsigned long long)needed_total);
+            atomicAdd(&slot[1], (unsigned long long)ng * tiles_here);
+        }
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            if (64 * it >= ng) break;
+            const int g = 64 * it + lane;
+            unsigned f = 0;
+#pragma unroll
+            for (int b = 0; b < NB; b++) f |= (unsigned)((need[b][it] >> lane) & 1ull) << b;
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(f != 0);
+            if (f != 0) glist[cnt + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(g | (f << 9));
+            cnt += __builtin_popcountll(bal);
+        }
+    } else {
         const long tile0 = pos0 / 32;
         for (int base = 0; base < ng; base += 64) {
             const int g = base + lane;
@@ -739,9 +873,18 @@ size_t at_filter_group_bytes(int d) { return group_bytes(d); }
 int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k, const uint32_t* order,
                     const int32_t* cperm, int ng, const float* bd, const uint32_t* mask, int ngw, int collect,
                     int64_t* ids, unsigned* misc, uint32_t* amb_list, uint32_t* amb_aux, float* approx_out,
-                    hipStream_t stream) {
+                    const uint32_t* fuse_hint_sorted, const float* fuse_dmin, float* fuse_bd_out, hipStream_t stream) {
     unsigned char* img = static_cast<unsigned char*>(at_ws(ctx, WS_CENT_IMG16, group_bytes(d) * (size_t)ng, stream));
     if (!img) return AT_E_NOMEM;
+    // fused pre-pass (exact calls only): the sweep computes the guess distances and its own group masks
+    const bool fused = fuse_hint_sorted && fuse_dmin && fuse_bd_out && collect;
+    FusedPrepass fp{fuse_hint_sorted, c, fuse_dmin, fuse_bd_out, nullptr, k};
+    if (fused) {
+        const bool fresh = ctx->ws[WS_PRUNE_STATS] == nullptr;
+        fp.stats = static_cast<unsigned long long*>(at_ws(ctx, WS_PRUNE_STATS, 4096, stream));
+        if (!fp.stats) return AT_E_NOMEM;
+        if (fresh) AT_HIP(hipMemsetAsync(fp.stats, 0, 4096, stream));
+    }
     hipLaunchKernelGGL(prep_centroids_f16_kernel, dim3(ng), dim3(WG), 0, stream, c, k, d, cperm, img);
     AT_LAUNCH_CHECK();
     AT_HIP(hipMemsetAsync(misc, 0, 64 * sizeof(unsigned), stream));  // max|c|^2, list length, statistics
@@ -762,22 +905,25 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
                 AT_HIP(hipEventCreateWithFlags(&ctx->filter_ev[i], hipEventDisableSystemFence));
         AT_HIP(hipEventRecord(ctx->filter_ev[0], stream));
     }
-#define AT_FILTER_LAUNCH(DD, NBB, GG, GRID)                                                                          \
-    hipLaunchKernelGGL((assign_f16filter_kernel<DD, NBB, GG>), GRID, dim3(64), 0, stream, x, (long)n, img, ng, order, bd, \
-                       mask, ngw, misc, ta, tb, ra, rb, screen, collect, reinterpret_cast<long*>(ids), amb_list, amb_aux, \
-                       approx_out)
+#define AT_FILTER_LAUNCH(DD, NBB, GG, FF, GRID)                                                                      \
+    hipLaunchKernelGGL((assign_f16filter_kernel<DD, NBB, GG, FF>), GRID, dim3(64), 0, stream, x, (long)n, img, ng, order, \
+                       bd, mask, ngw, misc, ta, tb, ra, rb, screen, collect, reinterpret_cast<long*>(ids), amb_list,      \
+                       amb_aux, approx_out, fp)
     // exact calls (collect) and guess generators are separate instantiations: the guess path's code
     // would otherwise cost the exact sweep registers it does not have
     const dim3 grid64((unsigned)((n + 63) / 64));
     if (d == 128) {  // two tiles per wave: the fragment sets of d = 128 leave no registers for four
-        if (collect) AT_FILTER_LAUNCH(128, 2, false, grid64);
-        else AT_FILTER_LAUNCH(128, 2, true, grid64);
+        if (fused) AT_FILTER_LAUNCH(128, 2, false, true, grid64);
+        else if (collect) AT_FILTER_LAUNCH(128, 2, false, false, grid64);
+        else AT_FILTER_LAUNCH(128, 2, true, false, grid64);
     } else if (NB == 4) {
-        if (collect) AT_FILTER_LAUNCH(64, 4, false, grid);
-        else AT_FILTER_LAUNCH(64, 4, true, grid);
+        if (fused) AT_FILTER_LAUNCH(64, 4, false, true, grid);
+        else if (collect) AT_FILTER_LAUNCH(64, 4, false, false, grid);
+        else AT_FILTER_LAUNCH(64, 4, true, false, grid);
     } else {
-        if (collect) AT_FILTER_LAUNCH(64, 2, false, grid);
-        else AT_FILTER_LAUNCH(64, 2, true, grid);
+        if (fused) AT_FILTER_LAUNCH(64, 2, false, true, grid);
+        else if (collect) AT_FILTER_LAUNCH(64, 2, false, false, grid);
+        else AT_FILTER_LAUNCH(64, 2, true, false, grid);
     }
 #undef AT_FILTER_LAUNCH
     AT_LAUNCH_CHECK();
