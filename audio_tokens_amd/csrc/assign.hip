@@ -1280,9 +1280,12 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
         uint32_t* aux = list + 4 * ((size_t)n + 64);
         int rc = at_filter_sweep(ctx, x, n, D, c, k, order, cperm, ng, bd, mask, ngw, mode == 0 ? 1 : 0, ids, misc, list,
                                  aux, nullptr, fuse ? hint_sorted : nullptr, fuse ? dmin : nullptr, fuse ? bd : nullptr,
-                                 stream);
+                                 fuse ? dist : nullptr, stream);
         if (rc) return rc;
-        if (dist) {
+        if (dist && fuse) {  // the sweep wrote the guess distances; the rows that moved get theirs here
+            rc = at_exact_dist_todo(ctx, x, n, D, c, k, ids, dist, stream);
+            if (rc) return rc;
+        } else if (dist) {
             rc = mode == 0 ? at_exact_dist_rows(ctx, x, n, D, c, k, ids, dist, order, hint_sorted, bd, stream)
                            : at_exact_dist_rows(ctx, x, n, D, c, k, ids, dist, nullptr, nullptr, nullptr, stream);
             if (rc) return rc;
@@ -1415,7 +1418,7 @@ extern "C" int at_filter_probe_f32(at_ctx* ctx, const float* x, int64_t n, int d
     int rc = at_prune_prepass(ctx, x, n, d, c, k, order, hint_sorted, dmin, ng, bd, mask, ngw, 0, stream);
     if (rc) return rc;
     rc = at_filter_sweep(ctx, x, n, d, c, k, order, cperm, ng, bd, mask, ngw, 1, ids, misc, list,
-                         list + 4 * ((size_t)n + 64), approx, nullptr, nullptr, nullptr, stream);
+                         list + 4 * ((size_t)n + 64), approx, nullptr, nullptr, nullptr, nullptr, stream);
     if (rc) return rc;
     unsigned cnt = 0;
     AT_HIP(hipMemcpyAsync(&cnt, misc + 1, sizeof cnt, hipMemcpyDeviceToHost, stream));

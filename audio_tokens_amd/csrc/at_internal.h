@@ -82,7 +82,10 @@ void* at_ws(at_ctx* ctx, int slot, size_t bytes, hipStream_t stream);
 int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k, const uint32_t* order,
                     const int32_t* cperm, int ng, const float* bd, const uint32_t* mask, int ngw, int collect,
                     int64_t* ids, unsigned* misc, uint32_t* amb_list, uint32_t* amb_aux, float* approx_out,
-                    const uint32_t* fuse_hint_sorted, const float* fuse_dmin, float* fuse_bd_out, hipStream_t stream);
+                    const uint32_t* fuse_hint_sorted, const float* fuse_dmin, float* fuse_bd_out, float* fuse_dist_out,
+                    hipStream_t stream);
+int at_exact_dist_todo(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k, const int64_t* ids,
+                       float* dist, hipStream_t stream);
 int at_exact_dist_rows(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k, const int64_t* ids,
                        float* dist, const uint32_t* order, const uint32_t* hint_sorted, const float* bd,
                        hipStream_t stream);

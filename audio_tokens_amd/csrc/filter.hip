@@ -124,9 +124,11 @@ struct FusedPrepass {
     const float* C;
     const float* dmin;
     float* bd_out;
+    float* dist_out;   // optional: the guess distance where the winner is the guess, DIST_TODO elsewhere
     unsigned long long* stats;
     int k;
 };
+constexpr unsigned DIST_TODO = 0x7fc0deadu;  // a NaN no computed distance can be
 
 template <int D, int NB, bool GUESS, bool FUSED>
 __global__ void __launch_bounds__(64, 2)
@@ -157,7 +159,8 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
     unsigned i1[NB], i2[NB];
     bool bad[NB];
     unsigned rowid[NB];
-    float mtau[FUSED ? NB : 1];      // fused pre-pass: the row's Elkan radius (2R) / its guess
+    float mtau[FUSED ? NB : 1];      // fused pre-pass: the row's Elkan radius (2R) / its guess / its distance
+    float gbd[FUSED ? NB : 1];
     uint32_t hintp[FUSED ? NB : 1];
 #pragma unroll
     for (int b = 0; b < NB; b++) {
@@ -219,6 +222,7 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
             // exactly the value the fp32 sweep would produce for (x, c_p)
             const float dh = __builtin_fmaxf(__builtin_fmaf(-2.0f, ip, xn + cn), 0.0f);
             bd = has ? dh : __builtin_inff();
+            gbd[b] = bd;
             if (h == 0 && pos0 + 32 * b + j < n) fp.bd_out[pos] = bd;
             const float delta = (2.0f * D + 8.0f) * 5.9604645e-8f * (xn + cnmax) * 1.01f;
             // rows without a guess need every group; positions past n need none
@@ -537,6 +541,10 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
         if (mine) {
             const unsigned id = slot_id(nj1);
             ids[rowid[b]] = id == NONE ? -1L : (long)id;
+            if constexpr (FUSED) {
+                if (fp.dist_out)
+                    fp.dist_out[rowid[b]] = (id != NONE && id == hintp[b]) ? gbd[b] : __uint_as_float(DIST_TODO);
+            }
             if (approx_out) {  // test hook: approximate distance of the winner and the gap to the runner-up
                 approx_out[2 * (size_t)rowid[b]] = n1;
                 approx_out[2 * (size_t)rowid[b] + 1] = n2 - n1;
@@ -617,6 +625,39 @@ __global__ void __launch_bounds__(WG) exact_dist_visit_kernel(const float* __res
     const f32x4* px = reinterpret_cast<const f32x4*>(X + i * D);
     const f32x4* pc = reinterpret_cast<const f32x4*>(C + p * D);
     f32x4 xv[D / 4], cv[D / 4];  // all loads in flight before the first dependent fma
+#pragma unroll
+    for (int q = 0; q < D / 4; q++) xv[q] = px[q];
+#pragma unroll
+    for (int q = 0; q < D / 4; q++) cv[q] = pc[q];
+    float xn = 0.0f, cn = 0.0f, ip = 0.0f;
+#pragma unroll
+    for (int q = 0; q < D / 4; q++) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            xn = __builtin_fmaf(xv[q][e], xv[q][e], xn);
+            cn = __builtin_fmaf(cv[q][e], cv[q][e], cn);
+            ip = __builtin_fmaf(cv[q][e], xv[q][e], ip);
+        }
+    }
+    dist[i] = __builtin_fmaxf(__builtin_fmaf(-2.0f, ip, xn + cn), 0.0f);
+}
+
+// After a fused sweep: rows whose winner is not their guess still need the contract's distance.
+template <int D>
+__global__ void __launch_bounds__(WG) exact_dist_todo_kernel(const float* __restrict__ X, long n,
+                                                             const float* __restrict__ C, int k,
+                                                             const long* __restrict__ ids,
+                                                             float* __restrict__ dist) {
+    const long i = (long)blockIdx.x * WG + threadIdx.x;
+    if (i >= n || __float_as_uint(dist[i]) != DIST_TODO) return;
+    const long p = ids[i];
+    if (p < 0 || p >= k) {
+        dist[i] = __builtin_inff();
+        return;
+    }
+    const f32x4* px = reinterpret_cast<const f32x4*>(X + i * D);
+    const f32x4* pc = reinterpret_cast<const f32x4*>(C + p * D);
+    f32x4 xv[D / 4], cv[D / 4];
 #pragma unroll
     for (int q = 0; q < D / 4; q++) xv[q] = px[q];
 #pragma unroll
@@ -873,12 +914,13 @@ size_t at_filter_group_bytes(int d) { return group_bytes(d); }
 int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k, const uint32_t* order,
                     const int32_t* cperm, int ng, const float* bd, const uint32_t* mask, int ngw, int collect,
                     int64_t* ids, unsigned* misc, uint32_t* amb_list, uint32_t* amb_aux, float* approx_out,
-                    const uint32_t* fuse_hint_sorted, const float* fuse_dmin, float* fuse_bd_out, hipStream_t stream) {
+                    const uint32_t* fuse_hint_sorted, const float* fuse_dmin, float* fuse_bd_out, float* fuse_dist_out,
+                    hipStream_t stream) {
     unsigned char* img = static_cast<unsigned char*>(at_ws(ctx, WS_CENT_IMG16, group_bytes(d) * (size_t)ng, stream));
     if (!img) return AT_E_NOMEM;
     // fused pre-pass (exact calls only): the sweep computes the guess distances and its own group masks
     const bool fused = fuse_hint_sorted && fuse_dmin && fuse_bd_out && collect;
-    FusedPrepass fp{fuse_hint_sorted, c, fuse_dmin, fuse_bd_out, nullptr, k};
+    FusedPrepass fp{fuse_hint_sorted, c, fuse_dmin, fuse_bd_out, fuse_dist_out, nullptr, k};
     if (fused) {
         const bool fresh = ctx->ws[WS_PRUNE_STATS] == nullptr;
         fp.stats = static_cast<unsigned long long*>(at_ws(ctx, WS_PRUNE_STATS, 4096, stream));
@@ -1013,6 +1055,21 @@ int at_group_min_dist_f16(at_ctx* ctx, const float* c, int k, int d, const int32
         hipLaunchKernelGGL(group_min_dist_f16_kernel<64>, grid, dim3(64), 0, stream, c, k, img, ng, misc, eps_a, eps_b, dmin);
     else
         hipLaunchKernelGGL(group_min_dist_f16_kernel<128>, grid, dim3(64), 0, stream, c, k, img, ng, misc, eps_a, eps_b, dmin);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}
+
+// Completes dist after a fused sweep that was given dist_out (see exact_dist_todo_kernel).
+int at_exact_dist_todo(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k, const int64_t* ids,
+                       float* dist, hipStream_t stream) {
+    (void)ctx;
+    const dim3 grid((unsigned)((n + WG - 1) / WG));
+    if (d == 64)
+        hipLaunchKernelGGL(exact_dist_todo_kernel<64>, grid, dim3(WG), 0, stream, x, (long)n, c, k,
+                           reinterpret_cast<const long*>(ids), dist);
+    else
+        hipLaunchKernelGGL(exact_dist_todo_kernel<128>, grid, dim3(WG), 0, stream, x, (long)n, c, k,
+                           reinterpret_cast<const long*>(ids), dist);
     AT_LAUNCH_CHECK();
     return AT_OK;
 }

@@ -172,7 +172,7 @@ def main():
 
     kinds = {kd: agg(kd) for kd in ("pruned", "coarse", "plain", "hinted")}
     filtered = f_sweeps > 0
-    names = {"pruned": ("at_assign_pruned_f32 exact call: assign_f16filter_kernel<64,4,false,true> + exact_dist_visit_kernel + fp32 redo "
+    names = {"pruned": ("at_assign_pruned_f32 exact call: assign_f16filter_kernel<64,4,false,true> + exact_dist_todo_kernel + fp32 redo "
                         "of the listed rows (exact_rows_kernel<64>)") if filtered
              else "assign_mfma_pruned_reg_kernel<64,2> (at_assign_pruned_f32, exact mode)",
              "coarse": ("assign_f16filter_kernel<64,4,true,false>" if filtered else "assign_mfma_pruned_reg_kernel<64,2>") + " (guess generator)",

@@ -22,7 +22,7 @@ for i, r in enumerate(tr):
     while j < len(tr) and ("rocclr" in tr[j]["Kernel_Name"]):   # skip the runtime's copy / fill kernels
         j += 1
     nxt = tr[j]["Kernel_Name"] if j < len(tr) else ""
-    if "exact_dist_visit" in nxt or "exact_rows" in nxt:
+    if "exact_dist_todo" in nxt or "exact_dist_visit" in nxt or "exact_rows" in nxt:
         exact.append(dur(r))
 out = os.path.join(root, "profiles", "r01_bench_kernel_stats_top.txt")
 with open(out, "w") as f:
@@ -33,7 +33,7 @@ with open(out, "w") as f:
     f.write("assign_f16filter_kernel<64,4,false,true>, the roofline kernel of bench.py:\n")
     for k, v in sorted(shapes.items()):
         f.write(f"  launches of {2 * k:>9d} rows ({k} threads, one wave per 128 rows): {len(v):4d}, avg {sum(v) / len(v):9.1f} us\n")
-    f.write(f"  exact-mode launches (followed by exact_dist_visit_kernel / exact_rows_kernel; 62 per pipeline run: 60 Lloyd sweeps of\n"
+    f.write(f"  exact-mode launches (followed by exact_dist_todo_kernel / exact_rows_kernel; 62 per pipeline run: 60 Lloyd sweeps of\n"
             f"  2 097 152 rows + the tokenise sweeps of 38.8 M and 4.3 M rows): {len(exact)} in this trace, avg {sum(exact) / max(1, len(exact)):.1f} us\n"
             f"  bench.py roofline.avg_launch_ms (HIP events around the same kernel, exact launches of the 3 timed steps): "
             f"{d['roofline']['avg_launch_ms'] * 1e3:.1f} us over {d['roofline']['launches']} launches\n\n")
