@@ -1280,16 +1280,15 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
         uint32_t* aux = list + 4 * ((size_t)n + 64);
         int rc = at_filter_sweep(ctx, x, n, D, c, k, order, cperm, ng, bd, mask, ngw, mode == 0 ? 1 : 0, ids, misc, list,
                                  aux, nullptr, fuse ? hint_sorted : nullptr, fuse ? dmin : nullptr, fuse ? bd : nullptr,
-                                 fuse ? dist : nullptr, stream);
+                                 (fuse || mode != 0) ? dist : nullptr, stream);
         if (rc) return rc;
         if (dist && fuse) {  // the sweep wrote the guess distances; the rows that moved get theirs here
             rc = at_exact_dist_todo(ctx, x, n, D, c, k, ids, dist, stream);
             if (rc) return rc;
-        } else if (dist) {
-            rc = mode == 0 ? at_exact_dist_rows(ctx, x, n, D, c, k, ids, dist, order, hint_sorted, bd, stream)
-                           : at_exact_dist_rows(ctx, x, n, D, c, k, ids, dist, nullptr, nullptr, nullptr, stream);
+        } else if (dist && mode == 0) {
+            rc = at_exact_dist_rows(ctx, x, n, D, c, k, ids, dist, order, hint_sorted, bd, stream);
             if (rc) return rc;
-        }
+        }  // (guess generators wrote an approximate distance themselves: it only orders the next visit)
         if (mode != 0) return AT_OK;
         unsigned host_misc[64];
         AT_HIP(hipMemcpyAsync(host_misc, misc, sizeof host_misc, hipMemcpyDeviceToHost, stream));

@@ -160,7 +160,7 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
     bool bad[NB];
     unsigned rowid[NB];
     float mtau[FUSED ? NB : 1];      // fused pre-pass: the row's Elkan radius (2R) / its guess / its distance
-    float gbd[FUSED ? NB : 1];
+    float gbd[(FUSED || GUESS) ? NB : 1];   // (guess generator: |x|^2, to turn P into an approximate distance)
     uint32_t hintp[FUSED ? NB : 1];
 #pragma unroll
     for (int b = 0; b < NB; b++) {
@@ -253,6 +253,7 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
         if constexpr (!FUSED) {
             nrm = part + __shfl_xor(part, 32);
             bd = bd_in[pos];
+            if constexpr (GUESS) gbd[b] = nrm;
         }
         tau[b] = __builtin_fmaf(tau_a, nrm * 1.001f + cnmax, tau_b);
         rho[b] = screen ? __builtin_fmaf(rho_a, nrm * 1.001f + cnmax, rho_b) : __builtin_inff();
@@ -544,6 +545,9 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
             if constexpr (FUSED) {
                 if (fp.dist_out)
                     fp.dist_out[rowid[b]] = (id != NONE && id == hintp[b]) ? gbd[b] : __uint_as_float(DIST_TODO);
+            }
+            if constexpr (GUESS) {  // a guess comes with an approximate distance (it only orders the next visit)
+                if (fp.dist_out) fp.dist_out[rowid[b]] = id != NONE ? __builtin_fmaxf(n1 + gbd[b], 0.0f) : __builtin_inff();
             }
             if (approx_out) {  // test hook: approximate distance of the winner and the gap to the runner-up
                 approx_out[2 * (size_t)rowid[b]] = n1;
@@ -920,7 +924,7 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
     if (!img) return AT_E_NOMEM;
     // fused pre-pass (exact calls only): the sweep computes the guess distances and its own group masks
     const bool fused = fuse_hint_sorted && fuse_dmin && fuse_bd_out && collect;
-    FusedPrepass fp{fuse_hint_sorted, c, fuse_dmin, fuse_bd_out, fuse_dist_out, nullptr, k};
+    FusedPrepass fp{fuse_hint_sorted, c, fuse_dmin, fuse_bd_out, fuse_dist_out, nullptr, k};  // (guess generators use dist_out only)
     if (fused) {
         const bool fresh = ctx->ws[WS_PRUNE_STATS] == nullptr;
         fp.stats = static_cast<unsigned long long*>(at_ws(ctx, WS_PRUNE_STATS, 4096, stream));
