@@ -15,7 +15,6 @@
 // ascending index; one wavefront then walks one list, lanes across the feature axis, so each
 // row is one coalesced 4d-byte read and the adds are sequential per (cluster, feature) exactly as
 // on the CPU.  No float atomics anywhere: results are bitwise reproducible.
-#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -148,7 +147,7 @@ __global__ void __launch_bounds__(WG) centroid_accum_long_kernel(const float* __
                                                                  const uint32_t* __restrict__ offsets,
                                                                  uint32_t long_list,
                                                                  float* __restrict__ sums,
-                                                                 float* __restrict__ counts, int std_pipeline) {
+                                                                 float* __restrict__ counts) {
     // feature-major ring: ring[buffer][feature][member], so an adder lane reads four consecutive members of
     // its feature with one 16-byte LDS read
     __shared__ __attribute__((aligned(16))) float ring[2][4][LONG_CHUNK];
@@ -200,37 +199,7 @@ __global__ void __launch_bounds__(WG) centroid_accum_long_kernel(const float* __
         } else if (tid < 4) {
             const float* src = ring[ch & 1][tid];
             const uint32_t cnt = min((uint32_t)LONG_CHUNK, len - ch * LONG_CHUNK);
-            // The adds are one dependent chain; the LDS reads of the next 16 members are issued before the
-            // chain of the current 16 (two register sets), so their latency is off the chain.
             uint32_t m = 0;
-            const bool pipelined = std_pipeline;
-            if (pipelined && cnt >= 16) {
-                float4 a[4], b[4];
-#define AT_LOAD16(T, M0)                                                        \
-    _Pragma("unroll") for (int u = 0; u < 4; u++) T[u] = *reinterpret_cast<const float4*>(src + (M0) + 4 * u)
-#define AT_ADD16(T)                                   \
-    _Pragma("unroll") for (int u = 0; u < 4; u++) {   \
-        acc += T[u].x;                                \
-        acc += T[u].y;                                \
-        acc += T[u].z;                                \
-        acc += T[u].w;                                \
-    }
-                AT_LOAD16(a, 0);
-                for (;;) {
-                    const bool hb = m + 32 <= cnt;
-                    if (hb) AT_LOAD16(b, m + 16);
-                    AT_ADD16(a);
-                    m += 16;
-                    if (!hb) break;
-                    const bool ha = m + 32 <= cnt;
-                    if (ha) AT_LOAD16(a, m + 16);
-                    AT_ADD16(b);
-                    m += 16;
-                    if (!ha) break;
-                }
-#undef AT_LOAD16
-#undef AT_ADD16
-            }
             for (; m + 16 <= cnt; m += 16) {
                 float4 t[4];
 #pragma unroll
@@ -430,9 +399,8 @@ int at_centroid_accum_f32(at_ctx* ctx, const float* x, int64_t n, int d, const i
         AT_HIP(hipEventRecord(ctx->side_ev[0], stream));
         AT_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->side_ev[0], 0));
         // (workgroups of short clusters exit at once; gridDim.y = feature slices)
-        const char* lp = std::getenv("AT_LONG_PIPE");  // A/B aid: 0 = reads and adds of a block back to back
         hipLaunchKernelGGL(centroid_accum_long_kernel, dim3(k, d / 4), dim3(WG), 0, ctx->side_stream, x, d, order,
-                           offsets, long_list, sums, counts, (lp && std::atoi(lp) == 0) ? 0 : 1);
+                           offsets, long_list, sums, counts);
         AT_LAUNCH_CHECK();
         AT_HIP(hipEventRecord(ctx->side_ev[1], ctx->side_stream));
     }
