@@ -332,11 +332,13 @@ class HipBackend(HostHelpers):
         guess, gdis = self.assign_pruned(x, c, self.visit_order(gx, None, ng), cperm, gnbr, mode=1)
         return self.assign_pruned(x, c, self.visit_order(guess, gdis, c.shape[0]), cperm, dmin, want_dist=want_dist)
 
-    def assign_pruned(self, x, c, order, cperm, dmin, want_dist=True, mode=0, filter=None):
+    def assign_pruned(self, x, c, order, cperm, dmin, want_dist=True, mode=0, filter=None, image_current=False):
         """mode 0: same result as assign(); `order` = visit_order(...) of the guesses.
         mode 1: best centroid among the groups named by each 32-row tile (order = visit_order of
         group ids) -- a guess generator.
-        filter (default: on unless AT_FILTER=0): fp16-split first stage, same bits out."""
+        filter (default: on unless AT_FILTER=0): fp16-split first stage, same bits out.
+        image_current: `dmin` was computed by group_min_dist(c, cperm) on these very tensors and nothing
+        has used the filter since, so the fp16 image of the centroids need not be rebuilt."""
         x, c = self._f32(x), self._f32(c)
         n, d = x.shape
         if filter is None:
@@ -359,7 +361,8 @@ class HipBackend(HostHelpers):
                 e0.record(torch.cuda.current_stream(self.device))
             _lib.check(self.lib.at_assign_pruned_f32(self.ctx.handle, _ptr(x), n, d, _ptr(c), k, _ptr(order),
                                                      _ptr(hint_sorted), _ptr(cperm), ng, _ptr(dmin),
-                                                     mode | (2 if use_filter else 0), 0 if fused else 1, _ptr(ids),
+                                                     mode | (2 if use_filter else 0),
+                                                     (0 if fused else 1) | (2 if image_current else 0), _ptr(ids),
                                                      _ptr(dist), self._stream()))
         if rec is not None:
             e1.record(torch.cuda.current_stream(self.device))

@@ -1255,9 +1255,17 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
     float* bd = static_cast<float*>(at_ws(ctx, WS_PRUNE_BD, sizeof(float) * (size_t)n, stream));
     uint32_t* mask = static_cast<uint32_t*>(at_ws(ctx, WS_PRUNE_MASK, sizeof(uint32_t) * (size_t)ntile32 * ngw, stream));
     if (!img || !bd || !mask) return AT_E_NOMEM;
-    // image: one tile per group (NA = 1): 32 rows, then |c|^2 at [0,32) and indices at [128,160)
-    hipLaunchKernelGGL(prep_centroids_perm_kernel, dim3(ng), dim3(WG), 0, stream, c, k, D, cperm, kp, 1, img);
-    AT_LAUNCH_CHECK();
+    // fp32 image (one tile per group, NA = 1: 32 rows, then |c|^2 at [0,32) and indices at [128,160)): built
+    // only where the fp32 sweep runs -- without the filter, or for its long-list redo
+    auto prep_fp32_image = [&]() -> int {
+        hipLaunchKernelGGL(prep_centroids_perm_kernel, dim3(ng), dim3(WG), 0, stream, c, k, D, cperm, kp, 1, img);
+        AT_LAUNCH_CHECK();
+        return AT_OK;
+    };
+    if (!filter) {
+        int rc = prep_fp32_image();
+        if (rc) return rc;
+    }
     // exact filtered calls without a pre-pass done by the caller: the sweep does it in its prologue
     const char* fz = std::getenv("AT_FILTER_FUSED");  // A/B aid: 0 = separate pre-pass kernel
     const bool fuse = filter && mode == 0 && !prepass_done && !(fz && std::atoi(fz) == 0);
@@ -1310,6 +1318,8 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
         // centroids outside the fp16 range): the fp32 MFMA sweep over the listed rows
         if ((int64_t)listed * 16 <= n)
             return at_filter_redo_rows(ctx, x, D, c, k, list, listed, order, cperm, dmin, ng, misc, aux, ids, dist, stream);
+        rc = prep_fp32_image();
+        if (rc) return rc;
         n2 = listed < 64 ? 64 : (int64_t)listed;
         uint32_t* sorted = list + ((size_t)n + 64);
         uint32_t* order_amb = sorted + ((size_t)n + 64);
@@ -1350,6 +1360,8 @@ extern "C" int at_assign_pruned_f32(at_ctx* ctx, const float* x, int64_t n, int 
                "at_assign_pruned_f32: bad sizes n=%lld k=%d ng=%d", (long long)n, k, ng);
     AT_REQUIRE(at_aligned16(x) && at_aligned16(c), "at_assign_pruned_f32: x and c must be 16-byte aligned");
     AT_HIP(hipSetDevice(ctx->device));
+    ctx->img16_trusted = (prepass_done & 2) != 0;  // consumed (and cleared) by the filter sweep
+    prepass_done &= 1;
     if (d == 64) {
         const char* e = std::getenv("AT_PRUNE_NB");
         if (e && std::atoi(e) == 4) return launch_pruned<64, 4>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, prepass_done != 0, filter, ids, dist, stream);

@@ -30,7 +30,6 @@ enum at_ws_slot {
     WS_VISIT_VALS_A,
     WS_VISIT_VALS_B,
     WS_VISIT_TMP,
-    WS_DMIN_MISC,      // group_min_dist on the matrix cores: max|c|^2 bits
     WS_FILTER_MISC,    // fp16-split filter: max|c|^2 bits, list length; running totals for at_filter_stats
     WS_NSLOTS
 };
@@ -51,6 +50,12 @@ struct at_ctx {
     hipStream_t side_stream;             // centroid_accum: long member lists beside the short ones
     hipEvent_t side_ev[2];
     int defer_join, join_pending;        // at_centroid_accum_defer / at_centroid_accum_join
+    // what at_group_min_dist_f32 left in WS_CENT_IMG16 / WS_FILTER_MISC[0]; a sweep may reuse it when its
+    // caller vouches (prepass_done bit 1) that the centroids are unchanged
+    const float* img16_c;
+    const int32_t* img16_cperm;
+    const unsigned* img16_misc;
+    int img16_k, img16_d, img16_ng, img16_trusted;
 };
 
 int at_fail(int code, const char* fmt, ...);

@@ -931,11 +931,21 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
         if (!fp.stats) return AT_E_NOMEM;
         if (fresh) AT_HIP(hipMemsetAsync(fp.stats, 0, 4096, stream));
     }
-    hipLaunchKernelGGL(prep_centroids_f16_kernel, dim3(ng), dim3(WG), 0, stream, c, k, d, cperm, img);
-    AT_LAUNCH_CHECK();
-    AT_HIP(hipMemsetAsync(misc, 0, 64 * sizeof(unsigned), stream));  // max|c|^2, list length, statistics
-    hipLaunchKernelGGL(max_sqnorm_bits_kernel, dim3((k + WG - 1) / WG), dim3(WG), 0, stream, c, k, d, misc);
-    AT_LAUNCH_CHECK();
+    // The image and max|c|^2 of exactly these centroids may be current already (at_group_min_dist_f32 built
+    // them, the caller vouches that the centroids have not changed since: prepass_done bit 1).
+    const bool reuse = ctx->img16_trusted && ctx->img16_c == c && ctx->img16_cperm == cperm && ctx->img16_k == k &&
+                       ctx->img16_d == d && ctx->img16_ng == ng && misc == ctx->img16_misc;
+    ctx->img16_trusted = 0;
+    if (reuse) {
+        AT_HIP(hipMemsetAsync(misc + 1, 0, 63 * sizeof(unsigned), stream));  // list length, statistics
+    } else {
+        ctx->img16_c = nullptr;
+        hipLaunchKernelGGL(prep_centroids_f16_kernel, dim3(ng), dim3(WG), 0, stream, c, k, d, cperm, img);
+        AT_LAUNCH_CHECK();
+        AT_HIP(hipMemsetAsync(misc, 0, 64 * sizeof(unsigned), stream));  // max|c|^2, list length, statistics
+        hipLaunchKernelGGL(max_sqnorm_bits_kernel, dim3((k + WG - 1) / WG), dim3(WG), 0, stream, c, k, d, misc);
+        AT_LAUNCH_CHECK();
+    }
     float ta = 0.0f, tb = 0.0f, ra = 0.0f, rb = 0.0f;
     filter_tau(d, &ta, &tb);
     filter_rho(d, &ra, &rb);
@@ -1041,13 +1051,15 @@ int at_filter_redo_rows(at_ctx* ctx, const float* x, int d, const float* c, int 
 int at_group_min_dist_f16(at_ctx* ctx, const float* c, int k, int d, const int32_t* cperm, int ng, float* dmin,
                           hipStream_t stream) {
     unsigned char* img = static_cast<unsigned char*>(at_ws(ctx, WS_CENT_IMG16, group_bytes(d) * (size_t)ng, stream));
-    unsigned* misc = static_cast<unsigned*>(at_ws(ctx, WS_DMIN_MISC, 256, stream));
+    unsigned* misc = static_cast<unsigned*>(at_ws(ctx, WS_FILTER_MISC, 256, stream));  // word 0 = max|c|^2, as the sweep wants it
     if (!img || !misc) return AT_E_NOMEM;
     hipLaunchKernelGGL(prep_centroids_f16_kernel, dim3(ng), dim3(WG), 0, stream, c, k, d, cperm, img);
     AT_LAUNCH_CHECK();
     AT_HIP(hipMemsetAsync(misc, 0, sizeof(unsigned), stream));
     hipLaunchKernelGGL(max_sqnorm_bits_kernel, dim3((k + WG - 1) / WG), dim3(WG), 0, stream, c, k, d, misc);
     AT_LAUNCH_CHECK();
+    ctx->img16_c = c; ctx->img16_cperm = cperm; ctx->img16_k = k; ctx->img16_d = d; ctx->img16_ng = ng;
+    ctx->img16_misc = misc;
     // eps of the filter's budget (header of this file) without the contract's delta: tau = 2 delta + 2 eps
     float ta = 0.0f, tb = 0.0f;
     filter_tau(d, &ta, &tb);

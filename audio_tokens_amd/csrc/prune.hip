@@ -300,6 +300,7 @@ int at_group_min_dist_f32(at_ctx* ctx, const float* c, int k, int d, const int32
     AT_HIP(hipSetDevice(ctx->device));
     const char* dv = std::getenv("AT_DMIN_KERNEL");  // A/B aid: 0 = the fp32 vector-ALU kernel below
     if (!(dv && std::atoi(dv) == 0)) return at_group_min_dist_f16(ctx, c, k, d, cperm, ng, dmin, stream);
+    ctx->img16_c = nullptr;  // (no fp16 image is left behind by this form)
     const dim3 grid(ng, (k + WG - 1) / WG);
     if (d == 64)
         hipLaunchKernelGGL(group_min_dist_kernel<64>, grid, dim3(WG), 0, stream, c, k, cperm, ng, dmin);

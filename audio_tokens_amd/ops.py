@@ -314,7 +314,7 @@ class Kmeans:
                     ids, dis = be.assign_c2f(xs, cent, cperm, dmin, gnbr)
                 else:
                     ids, dis = be.assign_pruned(xs, cent, vorder if vorder is not None else be.visit_order(ids, dis, k),
-                                                cperm, dmin)
+                                                cperm, dmin, image_current=True)
             elif ids is None:
                 ids, dis = be.assign(xs, cent)
             else:  # same answer, guided by the previous assignment and its member-list order
