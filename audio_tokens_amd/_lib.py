@@ -41,6 +41,7 @@ SIGNATURES = {
     "at_group_min_dist_f32": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "at_visit_order_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "at_prune_stats": (_i32, [_vp, _c.POINTER(_i64), _c.POINTER(_i64), _i32]),
+    "at_assign_coarse_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "at_filter_stats": (_i32, [_vp, _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_c.c_double), _c.POINTER(_i64),
                                _c.POINTER(_i64), _c.POINTER(_i64), _i32]),
     "at_filter_probe_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp,

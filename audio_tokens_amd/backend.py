@@ -320,14 +320,33 @@ class HipBackend(HostHelpers):
         _, order, zeros, perm, every = self._ident
         return self.assign_pruned(x, means, (order, zeros), perm, every, want_dist=False, mode=1, filter=True)[0]
 
-    def assign_c2f(self, x, c, cperm, dmin, gnbr=None, want_dist=True):
+    def assign_coarse(self, x, c, cperm, means, gnbr, want_dist=True):
+        """Guesses for rows in their own coherent order (frames of clips): nearest group mean -> its
+        neighbour groups -> best centroid among them, one launch (at_assign_coarse_f32)."""
+        x, c, means = self._f32(x), self._f32(c), self._f32(means)
+        n, d = x.shape
+        ng = cperm.numel() // 32
+        ids = self.empty((n,), torch.int64)
+        dist = self.empty((n,), torch.float32) if want_dist else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_assign_coarse_f32(self.ctx.handle, _ptr(x), n, d, _ptr(c), c.shape[0], _ptr(cperm), ng,
+                                                     _ptr(means), _ptr(gnbr), _ptr(ids), _ptr(dist), self._stream()))
+        return ids, dist
+
+    def assign_c2f(self, x, c, cperm, dmin, gnbr=None, want_dist=True, coherent=False):
         """Exact nearest centroid without guesses: nearest group mean -> best member of that group
-        and its neighbour groups (a guess) -> pruned exact sweep.  Same result as assign()."""
+        and its neighbour groups (a guess) -> pruned exact sweep.  Same result as assign().
+        coherent: the rows are in an order in which neighbours are alike (frames of clips): the guess
+        is then made in one launch without sorting the rows by mean first."""
         x, c = self._f32(x), self._f32(c)
         ng = cperm.numel() // 32
         means = self.group_means(c, cperm)
         if gnbr is None:
             gnbr = self.group_neighbours(means)
+        if (coherent and x.shape[1] in (64, 128) and os.environ.get("AT_FILTER", "1") != "0"
+                and os.environ.get("AT_C2F_FUSED", "1") != "0"):
+            guess, gdis = self.assign_coarse(x, c, cperm, means, gnbr)
+            return self.assign_pruned(x, c, self.visit_order(guess, gdis, c.shape[0]), cperm, dmin, want_dist=want_dist)
         gx = self._nearest_mean(x, means)
         guess, gdis = self.assign_pruned(x, c, self.visit_order(gx, None, ng), cperm, gnbr, mode=1)
         return self.assign_pruned(x, c, self.visit_order(guess, gdis, c.shape[0]), cperm, dmin, want_dist=want_dist)

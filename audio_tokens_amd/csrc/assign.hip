@@ -1437,3 +1437,18 @@ extern "C" int at_filter_probe_f32(at_ctx* ctx, const float* x, int64_t n, int d
     *listed = cnt;
     return AT_OK;
 }
+
+// Guess generator without a pre-sort, for rows whose own order is coherent (the frames of a clip follow
+// one another): nearest of the ng group means -> the groups its neighbour table names -> best centroid
+// among them, in one launch.  ids are guesses (feed at_visit_order_f32 / at_assign_pruned_f32), dist (optional)
+// approximate distances.
+extern "C" int at_assign_coarse_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
+                                    const int32_t* cperm, int ng, const float* means, const uint32_t* gnbr,
+                                    int64_t* ids, float* dist, void* stream_) {
+    AT_REQUIRE(ctx && x && c && cperm && means && gnbr && ids, "at_assign_coarse_f32: null pointer");
+    AT_REQUIRE((d == 64 || d == 128) && n >= 1 && n < (int64_t)UINT32_MAX && k > 0 && ng > 0 && ng <= 512 && ng * 32 >= k,
+               "at_assign_coarse_f32: bad sizes");
+    AT_REQUIRE(at_aligned16(x) && at_aligned16(c) && at_aligned16(means), "at_assign_coarse_f32: pointers must be 16-byte aligned");
+    AT_HIP(hipSetDevice(ctx->device));
+    return at_filter_coarse(ctx, x, n, d, c, k, cperm, ng, means, gnbr, ids, dist, (hipStream_t)stream_);
+}

@@ -30,6 +30,8 @@ enum at_ws_slot {
     WS_VISIT_VALS_A,
     WS_VISIT_VALS_B,
     WS_VISIT_TMP,
+    WS_CENT_IMG16B,    // fused coarse pass: fp16 image of the group means
+    WS_IOTA,           // fused coarse pass: identity permutation of the means
     WS_FILTER_MISC,    // fp16-split filter: max|c|^2 bits, list length; running totals for at_filter_stats
     WS_NSLOTS
 };
@@ -104,5 +106,8 @@ int at_filter_redo_rows(at_ctx* ctx, const float* x, int d, const float* c, int 
 
 int at_group_min_dist_f16(at_ctx* ctx, const float* c, int k, int d, const int32_t* cperm, int ng, float* dmin,
                           hipStream_t stream);
+
+int at_filter_coarse(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k, const int32_t* cperm, int ng,
+                     const float* means, const uint32_t* gnbr, int64_t* ids, float* dist, hipStream_t stream);
 
 static inline bool at_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -127,6 +127,11 @@ struct FusedPrepass {
     float* dist_out;   // optional: the guess distance where the winner is the guess, DIST_TODO elsewhere
     unsigned long long* stats;
     int k;
+    // guess generator over rows in their own order (frames of clips): nearest group mean first, then the
+    // groups its neighbour table names -- both inside one launch
+    const unsigned char* means_img;
+    const uint32_t* gnbr;
+    int ngm;
 };
 constexpr unsigned DIST_TODO = 0x7fc0deadu;  // a NaN no computed distance can be
 
@@ -142,6 +147,8 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
     constexpr int NS = D / 16;
     constexpr size_t GB = group_bytes(D);
     __shared__ unsigned short glist[512];
+    __shared__ uint32_t maskl[NB][16];   // (fused coarse mode) the tiles' group masks
+    const unsigned char* img_cur = img;  // the image the walk reads: the centroids', or first the group means'
     __shared__ half8 xl_lds[NB][D / 16][64];  // lo parts of the rows: only the rare refined tiles read them
 
     const int lane = threadIdx.x;
@@ -166,7 +173,7 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
     for (int b = 0; b < NB; b++) {
         long pos = pos0 + 32 * b + j;
         if (pos >= n) pos = n - 1;
-        const unsigned r = order[pos];
+        const unsigned r = order ? order[pos] : (unsigned)pos;
         rowid[b] = r;
         const f32x4* p = reinterpret_cast<const f32x4*>(X + (size_t)r * D);
         float part = 0.0f;
@@ -252,7 +259,7 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
         }
         if constexpr (!FUSED) {
             nrm = part + __shfl_xor(part, 32);
-            bd = bd_in[pos];
+            bd = bd_in ? bd_in[pos] : __builtin_inff();
             if constexpr (GUESS) gbd[b] = nrm;
         }
         tau[b] = __builtin_fmaf(tau_a, nrm * 1.001f + cnmax, tau_b);
@@ -341,24 +348,41 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
             cnt += __builtin_popcountll(bal);
         }
     } else {
-        const long tile0 = pos0 / 32;
-        for (int base = 0; base < ng; base += 64) {
-            const int g = base + lane;
-            unsigned f = 0;
-            if (g < ng) {
+        bool two_level = false;
+        if constexpr (GUESS) two_level = fp.means_img != nullptr;
+        if (two_level) {  // first walk: every group of the means image, every tile that exists
+            for (int base = 0; base < fp.ngm; base += 64) {
+                const int g = base + lane;
+                unsigned f = 0;
+                if (g < fp.ngm) {
 #pragma unroll
-                for (int b = 0; b < NB; b++)
-                    if (tile0 + b < ntile32) f |= ((mask[(size_t)(tile0 + b) * ngw + (g >> 5)] >> (g & 31)) & 1u) << b;
+                    for (int b = 0; b < NB; b++) f |= (unsigned)(pos0 + 32 * b < n) << b;
+                }
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(f != 0);
+                if (f != 0) glist[cnt + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(g | (f << 9));
+                cnt += __builtin_popcountll(bal);
             }
-            const unsigned long long bal = __builtin_amdgcn_ballot_w64(f != 0);
-            if (f != 0) glist[cnt + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(g | (f << 9));
-            cnt += __builtin_popcountll(bal);
+            img_cur = fp.means_img;
+        } else {
+            const long tile0 = pos0 / 32;
+            for (int base = 0; base < ng; base += 64) {
+                const int g = base + lane;
+                unsigned f = 0;
+                if (g < ng) {
+#pragma unroll
+                    for (int b = 0; b < NB; b++)
+                        if (tile0 + b < ntile32) f |= ((mask[(size_t)(tile0 + b) * ngw + (g >> 5)] >> (g & 31)) & 1u) << b;
+                }
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(f != 0);
+                if (f != 0) glist[cnt + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(g | (f << 9));
+                cnt += __builtin_popcountll(bal);
+            }
         }
     }
     auto entry = [&](int i) { return __builtin_amdgcn_readfirstlane((int)glist[i]); };
 
     auto load_group = [&](int g, half8 (&ah)[NS], f32x4 (&cn)[4]) {
-        const unsigned char* base = img + (size_t)g * GB;
+        const unsigned char* base = img_cur + (size_t)g * GB;
         const half8* fr = reinterpret_cast<const half8*>(base);
 #pragma unroll
         for (int s = 0; s < NS; s++) ah[s] = fr[s * 64 + lane];
@@ -432,7 +456,7 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
                 // every tile gets all three products (a guess made from hi*hi alone is measurably worse and
                 // costs the exact pass more than it saves here), but only the best candidate is kept
                 if (!have_al) {
-                    const half8* fr = reinterpret_cast<const half8*>(img + (size_t)g * GB + lo_off(D));
+                    const half8* fr = reinterpret_cast<const half8*>(img_cur + (size_t)g * GB + lo_off(D));
 #pragma unroll
                     for (int s = 0; s < NS; s++) al[s] = fr[s * 64 + lane];
                     have_al = true;
@@ -478,7 +502,7 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
             }
             if (!(pass0 || pass1)) continue;
             if (!have_al) {
-                const half8* fr = reinterpret_cast<const half8*>(img + (size_t)g * GB + lo_off(D));
+                const half8* fr = reinterpret_cast<const half8*>(img_cur + (size_t)g * GB + lo_off(D));
 #pragma unroll
                 for (int s = 0; s < NS; s++) al[s] = fr[s * 64 + lane];
                 have_al = true;
@@ -489,30 +513,69 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
         }
     };
 
-    // Two register sets alternate; the list entries are read from LDS two groups before they are
-    // needed (as a vector register, turned into a scalar only when used), so neither the LDS round trip
-    // nor the fragment loads it addresses sit in front of a group's MFMAs.
-    half8 ahA[NS], ahB[NS];
-    f32x4 cnA[4], cnB[4];
-    int e0 = -1, e1 = -1;
-    if (cnt > 0) {
-        e0 = entry(0);
-        load_group(e0 & 511, ahA, cnA);
-    }
-    if (cnt > 1) e1 = entry(1);
-    unsigned raw2 = cnt > 2 ? (unsigned)glist[2] : 0u;
-    for (int i = 0; i < cnt; i += 2) {
-        if (e1 >= 0) load_group(e1 & 511, ahB, cnB);
-        const unsigned raw3 = i + 3 < cnt ? (unsigned)glist[i + 3] : 0u;
-        compute_group(e0, ahA, cnA);
-        if (e1 < 0) break;
-        const int e0n = i + 2 < cnt ? __builtin_amdgcn_readfirstlane((int)raw2) : -1;
-        if (e0n >= 0) load_group(e0n & 511, ahA, cnA);
-        const unsigned raw4 = i + 4 < cnt ? (unsigned)glist[i + 4] : 0u;
-        compute_group(e1, ahB, cnB);
-        e0 = e0n;
-        e1 = i + 3 < cnt ? __builtin_amdgcn_readfirstlane((int)raw3) : -1;
-        raw2 = raw4;
+    auto run_sweep = [&]() {
+        // Two register sets alternate; the list entries are read from LDS two groups before they are
+        // needed (as a vector register, turned into a scalar only when used), so neither the LDS round trip
+        // nor the fragment loads it addresses sit in front of a group's MFMAs.
+        half8 ahA[NS], ahB[NS];
+        f32x4 cnA[4], cnB[4];
+        int e0 = -1, e1 = -1;
+        if (cnt > 0) {
+            e0 = entry(0);
+            load_group(e0 & 511, ahA, cnA);
+        }
+        if (cnt > 1) e1 = entry(1);
+        unsigned raw2 = cnt > 2 ? (unsigned)glist[2] : 0u;
+        for (int i = 0; i < cnt; i += 2) {
+            if (e1 >= 0) load_group(e1 & 511, ahB, cnB);
+            const unsigned raw3 = i + 3 < cnt ? (unsigned)glist[i + 3] : 0u;
+            compute_group(e0, ahA, cnA);
+            if (e1 < 0) break;
+            const int e0n = i + 2 < cnt ? __builtin_amdgcn_readfirstlane((int)raw2) : -1;
+            if (e0n >= 0) load_group(e0n & 511, ahA, cnA);
+            const unsigned raw4 = i + 4 < cnt ? (unsigned)glist[i + 4] : 0u;
+            compute_group(e1, ahB, cnB);
+            e0 = e0n;
+            e1 = i + 3 < cnt ? __builtin_amdgcn_readfirstlane((int)raw3) : -1;
+            raw2 = raw4;
+        }
+    };
+    run_sweep();
+    if constexpr (GUESS) {
+        if (fp.means_img != nullptr) {
+            // second walk: per tile the groups the neighbour table names for its rows' nearest means
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                const float o1 = __shfl_xor(b1[b], 32);
+                const unsigned oi = (unsigned)__shfl_xor((int)i1[b], 32);
+                const unsigned slot = o1 < b1[b] ? oi : i1[b];
+                const unsigned gm = slot == NONE ? NONE
+                    : reinterpret_cast<const unsigned*>(img_cur + (size_t)(slot >> 5) * GB + misc_off(D) + 128)[slot & 31];
+                const bool live = pos0 + 32 * b + j < n && gm != NONE && gm < (unsigned)ng;
+                for (int w = 0; w < ngw; w++) {
+                    uint32_t v = live ? fp.gnbr[(size_t)gm * ngw + w] : 0u;
+#pragma unroll
+                    for (int off = 16; off > 0; off >>= 1) v |= (uint32_t)__shfl_xor((int)v, off);
+                    if (lane == 0) maskl[b][w] = v;
+                }
+                b1[b] = b2[b] = b3[b] = __builtin_inff();
+                i1[b] = i2[b] = NONE;
+            }
+            img_cur = img;
+            cnt = 0;
+            for (int base = 0; base < ng; base += 64) {
+                const int g = base + lane;
+                unsigned f = 0;
+                if (g < ng) {
+#pragma unroll
+                    for (int b = 0; b < NB; b++) f |= ((maskl[b][g >> 5] >> (g & 31)) & 1u) << b;
+                }
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(f != 0);
+                if (f != 0) glist[cnt + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(g | (f << 9));
+                cnt += __builtin_popcountll(bal);
+            }
+            run_sweep();
+        }
     }
 
     if (lane == 0) {  // statistics only, spread over 16 slot pairs
@@ -521,7 +584,7 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
     }
     auto slot_id = [&](unsigned slot) {
         return slot == NONE ? NONE
-                            : reinterpret_cast<const unsigned*>(img + (size_t)(slot >> 5) * GB + misc_off(D) + 128)[slot & 31];
+                            : reinterpret_cast<const unsigned*>(img_cur + (size_t)(slot >> 5) * GB + misc_off(D) + 128)[slot & 31];
     };
 #pragma unroll
     for (int b = 0; b < NB; b++) {
@@ -1086,6 +1149,59 @@ int at_exact_dist_todo(at_ctx* ctx, const float* x, int64_t n, int d, const floa
     else
         hipLaunchKernelGGL(exact_dist_todo_kernel<128>, grid, dim3(WG), 0, stream, x, (long)n, c, k,
                            reinterpret_cast<const long*>(ids), dist);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}
+
+namespace {
+__global__ void __launch_bounds__(WG) iota_pad_kernel(int32_t* __restrict__ perm, int n_live, int n_total) {
+    const int i = blockIdx.x * WG + threadIdx.x;
+    if (i < n_total) perm[i] = i < n_live ? i : -1;
+}
+}  // namespace
+
+// Guess generator for rows whose own order is coherent (consecutive frames of clips): per 32-row tile the
+// nearest of the ng group means decides, through the neighbour table gnbr [ng][ceil(ng/32)], which groups
+// of centroids are searched -- one launch, rows read once (assign.hip: at_assign_coarse_f32).
+int at_filter_coarse(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k, const int32_t* cperm, int ng,
+                     const float* means, const uint32_t* gnbr, int64_t* ids, float* dist, hipStream_t stream) {
+    const int ngm = (ng + 31) / 32;              // groups of the means image
+    const int ngw = (ng + 31) / 32;
+    unsigned char* img = static_cast<unsigned char*>(at_ws(ctx, WS_CENT_IMG16, group_bytes(d) * (size_t)ng, stream));
+    unsigned char* img_m = static_cast<unsigned char*>(at_ws(ctx, WS_CENT_IMG16B, group_bytes(d) * (size_t)ngm, stream));
+    int32_t* perm_m = static_cast<int32_t*>(at_ws(ctx, WS_IOTA, sizeof(int32_t) * (size_t)ngm * 32, stream));
+    unsigned* misc = static_cast<unsigned*>(at_ws(ctx, WS_FILTER_MISC, 256, stream));
+    if (!img || !img_m || !perm_m || !misc) return AT_E_NOMEM;
+    ctx->img16_c = nullptr;
+    hipLaunchKernelGGL(iota_pad_kernel, dim3((ngm * 32 + WG - 1) / WG), dim3(WG), 0, stream, perm_m, ng, ngm * 32);
+    hipLaunchKernelGGL(prep_centroids_f16_kernel, dim3(ngm), dim3(WG), 0, stream, means, ng, d, perm_m, img_m);
+    hipLaunchKernelGGL(prep_centroids_f16_kernel, dim3(ng), dim3(WG), 0, stream, c, k, d, cperm, img);
+    AT_LAUNCH_CHECK();
+    AT_HIP(hipMemsetAsync(misc, 0, 64 * sizeof(unsigned), stream));
+    hipLaunchKernelGGL(max_sqnorm_bits_kernel, dim3((k + WG - 1) / WG), dim3(WG), 0, stream, c, k, d, misc);
+    AT_LAUNCH_CHECK();
+    float ta = 0.0f, tb = 0.0f, ra = 0.0f, rb = 0.0f;
+    filter_tau(d, &ta, &tb);
+    filter_rho(d, &ra, &rb);
+    FusedPrepass fp{};
+    fp.dist_out = dist;
+    fp.k = k;
+    fp.means_img = img_m;
+    fp.gnbr = gnbr;
+    fp.ngm = ngm;
+    const float* no_bd = nullptr;
+    const uint32_t* no_mask = nullptr;
+    const uint32_t* no_order = nullptr;
+    uint32_t* no_list = nullptr;
+    float* no_approx = nullptr;
+    if (d == 128)
+        hipLaunchKernelGGL((assign_f16filter_kernel<128, 2, true, false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, x,
+                           (long)n, img, ng, no_order, no_bd, no_mask, ngw, misc, ta, tb, ra, rb, 1, 0,
+                           reinterpret_cast<long*>(ids), no_list, no_list, no_approx, fp);
+    else
+        hipLaunchKernelGGL((assign_f16filter_kernel<64, 4, true, false>), dim3((unsigned)((n + 127) / 128)), dim3(64), 0, stream, x,
+                           (long)n, img, ng, no_order, no_bd, no_mask, ngw, misc, ta, tb, ra, rb, 1, 0,
+                           reinterpret_cast<long*>(ids), no_list, no_list, no_approx, fp);
     AT_LAUNCH_CHECK();
     return AT_OK;
 }

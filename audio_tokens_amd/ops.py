@@ -374,6 +374,7 @@ class IndexFlatL2:
         self._c = None
         self._prune = None   # (cperm, dmin, gnbr) for the coarse-to-fine exact search, built lazily
         self.prune = True
+        self.rows_coherent = True   # queries arrive as consecutive frames of clips (spec_tokenizer.py:66-78)
 
     @property
     def ntotal(self) -> int:
@@ -401,7 +402,7 @@ class IndexFlatL2:
                 cperm = be.from_host(be.group_rows_kd(be.to_host(c)))
                 self._prune = (cperm, be.group_min_dist(c, cperm), be.group_neighbours(be.group_means(c, cperm), 8))
             cperm, dmin, gnbr = self._prune
-            return be.assign_c2f(x, c, cperm, dmin, gnbr, want_dist=want_dist)
+            return be.assign_c2f(x, c, cperm, dmin, gnbr, want_dist=want_dist, coherent=self.rows_coherent)
         return be.assign(x, c, want_dist=want_dist)
 
     def search(self, x, k=1):

@@ -176,6 +176,14 @@ int at_prune_mask_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float
  * tiles it multiplied (hi*hi: d/16 MFMAs) / refined (2 d/16 more) (NULL to skip any of them);
  * at_filter_probe_f32 is a test hook (stage 1 only; approx[2i], approx[2i+1] = approximate
  * |c|^2 - 2 x.c of the winner and its gap to the runner-up). */
+/* Guess generator for rows in their own (coherent) order -- consecutive frames of clips, i.e. tokenise:
+ * nearest of the ng group means (means [ng, d], at_group_means_f32) -> the groups the neighbour table
+ * gnbr [ng][ceil(ng/32)] names -> best centroid among them, one launch, rows read once.  ids are guesses
+ * for at_visit_order_f32 / at_assign_pruned_f32; dist (may be NULL) approximate distances. */
+int at_assign_coarse_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
+                         const int32_t* cperm, int ng, const float* means, const uint32_t* gnbr,
+                         int64_t* ids, float* dist, void* stream);
+
 int at_filter_stats(at_ctx* ctx, int64_t* rows, int64_t* listed, double* sweep_ms, int64_t* sweeps,
                     int64_t* tiles, int64_t* refined, int reset);
 int at_filter_probe_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,

@@ -123,6 +123,9 @@ def test_assign_pruned_is_exact(be, oracle, monkeypatch, n, d, k, lds_kernel):
     # unguided coarse-to-fine search: same answer again
     ids, dis = be.assign_c2f(xt, ct, cperm, dmin)
     assert np.array_equal(ids.cpu().numpy(), ids_o) and np.array_equal(bits(dis.cpu().numpy()), bits(dis_o))
+    # ... and with the one-launch guess generator for rows in their own order
+    ids, dis = be.assign_c2f(xt, ct, cperm, dmin, coherent=True)
+    assert np.array_equal(ids.cpu().numpy(), ids_o) and np.array_equal(bits(dis.cpu().numpy()), bits(dis_o))
     # the visiting order is a permutation sorted by guess
     order, hs = be.visit_order(truth, dtruth, k)
     o = order.cpu().numpy().view(np.uint32).astype(np.int64)
