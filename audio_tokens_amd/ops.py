@@ -18,6 +18,7 @@ rows and the per-cluster partial sums/counts are exchanged once per iteration.
 """
 from __future__ import annotations
 
+import os
 import sys
 import time
 from collections import OrderedDict
@@ -400,7 +401,8 @@ class IndexFlatL2:
                 and (k + 31) // 32 <= 512 and x.shape[0] >= 65536):
             if self._prune is None:
                 cperm = be.from_host(be.group_rows_kd(be.to_host(c)))
-                self._prune = (cperm, be.group_min_dist(c, cperm), be.group_neighbours(be.group_means(c, cperm), 8))
+                # 4 neighbour groups for the one-launch guess generator (measured: 1-4 equal, 8 is 6 % slower)
+                self._prune = (cperm, be.group_min_dist(c, cperm), be.group_neighbours(be.group_means(c, cperm), 4))
             cperm, dmin, gnbr = self._prune
             return be.assign_c2f(x, c, cperm, dmin, gnbr, want_dist=want_dist, coherent=self.rows_coherent)
         return be.assign(x, c, want_dist=want_dist)
