@@ -398,3 +398,35 @@ def test_token_histogram(be, k):
     want = np.bincount(ids[ids >= 0], minlength=k)
     assert got.dtype == np.int64 and np.array_equal(got, want)
     assert int(be.token_histogram(np.zeros(0, np.int64), k).sum()) == 0
+
+
+def test_full_size_lloyd_shape_properties(be):
+    """BASELINE.json configs[3]'s Lloyd shape (2 097 152 rows x 8192 centroids x 64) is beyond the CPU
+    oracle's reach in a test, so the exact pruned + filtered sweep is held to size-independent
+    properties there: bit equality with the dense fp32 sweep (itself pinned to the oracle at small
+    sizes), every centroid is its own nearest neighbour at distance 0, no sampled centroid is closer
+    than the reported one, and a second sweep guided by the result reproduces it."""
+    from audio_tokens_amd.synth import synth_clips
+    wave = synth_clips(1218, L=220500, seed=4242, device=be.device)
+    x = be.logmel(wave, 22050, 512, 128, 64, frame_major=True, l2norm=True)
+    n, d, k = x.shape[0], 64, 8192
+    assert n >= 2097152
+    x = x[:2097152].contiguous()
+    n = x.shape[0]
+    g = torch.Generator(device="cuda").manual_seed(3)
+    pick = torch.randperm(n, device="cuda", generator=g)[:k]
+    c = x[pick].clone()
+    c += 1e-3 * torch.randn(k, d, device="cuda", generator=g)      # distinct centroids (silent frames repeat)
+    ids_d, dis_d = be.assign(x, c)                                  # dense fp32 sweep
+    cperm = be.from_host(be.group_rows_kd(be.to_host(c)))
+    dmin = be.group_min_dist(c, cperm)
+    ids_c, dis_c = be.assign_c2f(x, c, cperm, dmin, coherent=True)  # guess generator + fused filtered sweep
+    assert torch.equal(ids_c, ids_d) and torch.equal(dis_c.view(torch.int32), dis_d.view(torch.int32))
+    ids_p, dis_p = be.assign_pruned(x, c, be.visit_order(ids_d, dis_d, k), cperm, dmin)   # guided by the answer
+    assert torch.equal(ids_p, ids_d) and torch.equal(dis_p.view(torch.int32), dis_d.view(torch.int32))
+    own, own_d = be.assign_c2f(c.repeat(16, 1), c, cperm, dmin)      # 131 072 queries = the centroids themselves
+    assert torch.equal(own.view(16, k), torch.arange(k, device="cuda").expand(16, k)) and float(own_d.max()) == 0.0
+    probe = torch.randint(0, k, (n,), device="cuda", generator=g)   # a random other centroid per row is never closer
+    d_probe = ((x - c[probe]) ** 2).sum(1)
+    assert bool((dis_d <= d_probe + 1e-5).all())
+    assert int(torch.bincount(ids_d, minlength=k).sum()) == n
