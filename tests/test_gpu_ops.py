@@ -430,3 +430,30 @@ def test_full_size_lloyd_shape_properties(be):
     d_probe = ((x - c[probe]) ** 2).sum(1)
     assert bool((dis_d <= d_probe + 1e-5).all())
     assert int(torch.bincount(ids_d, minlength=k).sum()) == n
+
+
+def test_full_size_kmeans_is_independent_of_the_acceleration(be, monkeypatch):
+    """One FAISS-recipe training at the benchmark's size (2.1 M rows, 8192 clusters): the fp16-split
+    filter + fused pre-pass + exact pruning must leave centroids and objectives exactly where the
+    plain pruned fp32 sweep puts them, and the objective must not rise between Lloyd iterations."""
+    import warnings
+    from audio_tokens_amd.ops import Kmeans
+    from audio_tokens_amd.synth import synth_clips
+    wave = synth_clips(1218, L=220500, seed=99, device=be.device)
+    x = be.logmel(wave, 22050, 512, 128, 64, frame_major=True, l2norm=True)[:2097152].contiguous()
+    runs = {}
+    for label, env in (("filtered", {}), ("fp32", {"AT_FILTER": "0"})):
+        for key in ("AT_FILTER",):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        km = Kmeans(64, 8192, niter=4, backend=be)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            km.train(x)
+        runs[label] = (km.centroids_device.clone(), [s["obj"] for s in km.iteration_stats], [s["nsplit"] for s in km.iteration_stats])
+    monkeypatch.delenv("AT_FILTER", raising=False)
+    (ca, oa, sa), (cb, ob, sb) = runs["filtered"], runs["fp32"]
+    assert torch.equal(ca.view(torch.int32), cb.view(torch.int32))
+    assert oa == ob and sa == sb
+    assert all(later <= earlier * (1 + 1e-6) for earlier, later in zip(oa[1:], oa[2:]))   # (iteration 1 may repair empties)
