@@ -135,8 +135,8 @@ struct FusedPrepass {
 };
 constexpr unsigned DIST_TODO = 0x7fc0deadu;  // a NaN no computed distance can be
 
-template <int D, int NB, bool GUESS, bool FUSED>
-__global__ void __launch_bounds__(64, 2)
+template <int D, int NB, bool GUESS, bool FUSED, int WPS = 2>
+__global__ void __launch_bounds__(64, WPS)
 assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char* __restrict__ img, int ng,
                         const uint32_t* __restrict__ order, const float* __restrict__ bd_in,
                         const uint32_t* __restrict__ mask, int ngw, unsigned* __restrict__ misc, float tau_a,
@@ -148,6 +148,10 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
     constexpr size_t GB = group_bytes(D);
     __shared__ unsigned short glist[512];
     __shared__ uint32_t maskl[NB][16];   // (fused coarse mode) the tiles' group masks
+    // per-row values that only the epilogue needs sit out the walk in LDS (the walk is short of registers)
+    constexpr bool STASH = NB == 2;      // (four tiles already fill the CU's LDS with the lo parts of the rows)
+    __shared__ float stash_tau[STASH ? NB : 1][64], stash_gbd[STASH ? NB : 1][64];
+    __shared__ unsigned stash_row[STASH ? NB : 1][64], stash_hint[STASH ? NB : 1][64];
     const unsigned char* img_cur = img;  // the image the walk reads: the centroids', or first the group means'
     __shared__ half8 xl_lds[NB][D / 16][64];  // lo parts of the rows: only the rare refined tiles read them
 
@@ -513,10 +517,30 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
         }
     };
 
+    if constexpr (STASH) {
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            stash_tau[b][lane] = bad[b] ? -1.0f : tau[b];          // (a negative threshold stands for "not sane")
+            stash_row[b][lane] = rowid[b];
+            if constexpr (FUSED || GUESS) stash_gbd[b][lane] = gbd[b];
+            if constexpr (FUSED) stash_hint[b][lane] = hintp[b];
+        }
+    }
     auto run_sweep = [&]() {
         // Two register sets alternate; the list entries are read from LDS two groups before they are
         // needed (as a vector register, turned into a scalar only when used), so neither the LDS round trip
         // nor the fragment loads it addresses sit in front of a group's MFMAs.
+        if constexpr (WPS >= 3) {
+            // experiment: three waves per SIMD hide the fragment loads instead of a second register set
+            half8 ah[NS];
+            f32x4 cn[4];
+            for (int i = 0; i < cnt; i++) {
+                const int e = entry(i);
+                load_group(e & 511, ah, cn);
+                compute_group(e, ah, cn);
+            }
+            return;
+        }
         half8 ahA[NS], ahB[NS];
         f32x4 cnA[4], cnB[4];
         int e0 = -1, e1 = -1;
@@ -598,23 +622,36 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
         insert3(o3, NONE, n1, n2, n3, nj1, nj2);
         const long pos = pos0 + 32 * b + j;
         const bool mine = h == 0 && pos < n;
-        const bool sane = nj1 != NONE && !bad[b] && n1 > -__builtin_inff();
-        const bool unique = sane && (n2 - n1) > tau[b];
+        float tau_b, gbd_b = 0.0f;
+        unsigned row_b, hint_b = NONE;
+        if constexpr (STASH) {
+            tau_b = stash_tau[b][lane];
+            row_b = stash_row[b][lane];
+            if constexpr (FUSED || GUESS) gbd_b = stash_gbd[b][lane];
+            if constexpr (FUSED) hint_b = stash_hint[b][lane];
+        } else {
+            tau_b = bad[b] ? -1.0f : tau[b];
+            row_b = rowid[b];
+            if constexpr (FUSED || GUESS) gbd_b = gbd[b];
+            if constexpr (FUSED) hint_b = hintp[b];
+        }
+        const bool sane = nj1 != NONE && tau_b >= 0.0f && n1 > -__builtin_inff();
+        const bool unique = sane && (n2 - n1) > tau_b;
         // exactly two candidates within reach: the redo only has to score those two
-        const bool pair = sane && nj2 != NONE && (n3 - n1) > tau[b];
+        const bool pair = sane && nj2 != NONE && (n3 - n1) > tau_b;
         if (mine) {
             const unsigned id = slot_id(nj1);
-            ids[rowid[b]] = id == NONE ? -1L : (long)id;
+            ids[row_b] = id == NONE ? -1L : (long)id;
             if constexpr (FUSED) {
                 if (fp.dist_out)
-                    fp.dist_out[rowid[b]] = (id != NONE && id == hintp[b]) ? gbd[b] : __uint_as_float(DIST_TODO);
+                    fp.dist_out[row_b] = (id != NONE && id == hint_b) ? gbd_b : __uint_as_float(DIST_TODO);
             }
             if constexpr (GUESS) {  // a guess comes with an approximate distance (it only orders the next visit)
-                if (fp.dist_out) fp.dist_out[rowid[b]] = id != NONE ? __builtin_fmaxf(n1 + gbd[b], 0.0f) : __builtin_inff();
+                if (fp.dist_out) fp.dist_out[row_b] = id != NONE ? __builtin_fmaxf(n1 + gbd_b, 0.0f) : __builtin_inff();
             }
             if (approx_out) {  // test hook: approximate distance of the winner and the gap to the runner-up
-                approx_out[2 * (size_t)rowid[b]] = n1;
-                approx_out[2 * (size_t)rowid[b] + 1] = n2 - n1;
+                approx_out[2 * (size_t)row_b] = n1;
+                approx_out[2 * (size_t)row_b + 1] = n2 - n1;
             }
         }
         if (collect) {
@@ -1014,8 +1051,13 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
     filter_rho(d, &ra, &rb);
     const char* sc = std::getenv("AT_FILTER_SCREEN");  // A/B aid: 0 = always evaluate all three products
     const int screen = (sc && std::atoi(sc) == 0) ? 0 : 1;
-    const char* nbv = std::getenv("AT_FILTER_NB");  // A/B aid: rows per wave = 32 * NB
-    const int NB = (nbv && std::atoi(nbv) == 2) ? 2 : 4;
+    // Rows per wave = 32 * NB.  Lloyd-sized exact sweeps (rows sorted by guess, <= 8 M of them) run two
+    // tiles per wave at three waves per SIMD (168 registers, no second fragment set: occupancy hides the
+    // loads; 3 % faster than four tiles at two waves); the long tokenise sweeps and the guess generators
+    // keep four tiles per wave.  AT_FILTER_NB=2|4 forces the choice (A/B aid).
+    const char* nbv = std::getenv("AT_FILTER_NB");
+    const bool wps3 = fused && d == 64 && (nbv ? std::atoi(nbv) == 2 : n <= (int64_t)8 << 20) && !std::getenv("AT_FILTER_WPS2");
+    const int NB = (wps3 || (nbv && std::atoi(nbv) == 2)) ? 2 : 4;
     const dim3 grid((unsigned)((n + 32 * NB - 1) / (32 * NB)));
     AT_REQUIRE(d == 64 || d == 128, "at_filter_sweep: d must be 64 or 128");
     if (collect) {  // exact calls synchronise anyway: time the kernel for at_filter_stats
@@ -1040,7 +1082,11 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
         else if (collect) AT_FILTER_LAUNCH(64, 4, false, false, grid);
         else AT_FILTER_LAUNCH(64, 4, true, false, grid);
     } else {
-        if (fused) AT_FILTER_LAUNCH(64, 2, false, true, grid);
+        if (wps3) {
+            hipLaunchKernelGGL((assign_f16filter_kernel<64, 2, false, true, 3>), grid, dim3(64), 0, stream, x, (long)n, img, ng,
+                               order, bd, mask, ngw, misc, ta, tb, ra, rb, screen, collect, reinterpret_cast<long*>(ids),
+                               amb_list, amb_aux, approx_out, fp);
+        } else if (fused) AT_FILTER_LAUNCH(64, 2, false, true, grid);
         else if (collect) AT_FILTER_LAUNCH(64, 2, false, false, grid);
         else AT_FILTER_LAUNCH(64, 2, true, false, grid);
     }

@@ -172,7 +172,7 @@ def main():
 
     kinds = {kd: agg(kd) for kd in ("pruned", "coarse", "plain", "hinted")}
     filtered = f_sweeps > 0
-    names = {"pruned": ("at_assign_pruned_f32 exact call: assign_f16filter_kernel<64,4,false,true> + exact_dist_todo_kernel + fp32 redo "
+    names = {"pruned": ("at_assign_pruned_f32 exact call: assign_f16filter_kernel<64,2,false,true,3> + exact_dist_todo_kernel + fp32 redo "
                         "of the listed rows (exact_rows_kernel<64>)") if filtered
              else "assign_mfma_pruned_reg_kernel<64,2> (at_assign_pruned_f32, exact mode)",
              "coarse": ("assign_f16filter_kernel<64,4,true,false>" if filtered else "assign_mfma_pruned_reg_kernel<64,2>") + " (guess generator)",
@@ -209,7 +209,7 @@ def main():
         roofline = {
             "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-            "kernel": "assign_f16filter_kernel<64,4,false,true> (stage 1 of at_assign_pruned_f32, exact mode)",
+            "kernel": "assign_f16filter_kernel<64,2,false,true,3> (stage 1 of at_assign_pruned_f32, exact mode)",
             "launches": f_sweeps, "avg_launch_ms": f_ms / f_sweeps, "flop_per_launch": flop / f_sweeps,
             "share_of_step_time": (f_ms * 1e-3) / elapsed if elapsed > 0 else None,
             "rows_listed_for_fp32_redo_fraction": f_listed / f_rows if f_rows else None,

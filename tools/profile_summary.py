@@ -16,7 +16,7 @@ exact = []
 for i, r in enumerate(tr):
     if "f16filter" not in r["Kernel_Name"]:
         continue
-    if "false, true>" in r["Kernel_Name"]:
+    if "false, true" in r["Kernel_Name"]:
         shapes[int(r["Grid_Size_X"])].append(dur(r))
     j = i + 1
     while j < len(tr) and ("rocclr" in tr[j]["Kernel_Name"]):   # skip the runtime's copy / fill kernels
@@ -30,9 +30,9 @@ with open(out, "w") as f:
     f.write("5 pipeline runs in the process (1 warm-up + 3 timed + 1 per-stage split); the synthetic-data generation "
             "(at::native kernels) is part of the totals.\n")
     f.write(f"bench line of this run: {d['value']:.4g} frames/s, {d['ms_per_step']:.1f} ms/step\n\n")
-    f.write("assign_f16filter_kernel<64,4,false,true>, the roofline kernel of bench.py:\n")
+    f.write("assign_f16filter_kernel<D,NB,GUESS=false,FUSED=true[,WPS]>, the roofline kernel of bench.py (<64,2,false,true,3> for the Lloyd sweeps, <64,4,false,true> for the long tokenise sweeps):\n")
     for k, v in sorted(shapes.items()):
-        f.write(f"  launches of {2 * k:>9d} rows ({k} threads, one wave per 128 rows): {len(v):4d}, avg {sum(v) / len(v):9.1f} us\n")
+        f.write(f"  launches of {k:>9d} threads (one 64-lane wave per 64 rows in the <64,2,..,3> form, per 128 rows in <64,4,..>): {len(v):4d}, avg {sum(v) / len(v):9.1f} us\n")
     f.write(f"  exact-mode launches (followed by exact_dist_todo_kernel / exact_rows_kernel; 62 per pipeline run: 60 Lloyd sweeps of\n"
             f"  2 097 152 rows + the tokenise sweeps of 38.8 M and 4.3 M rows): {len(exact)} in this trace, avg {sum(exact) / max(1, len(exact)):.1f} us\n"
             f"  bench.py roofline.avg_launch_ms (HIP events around the same kernel, exact launches of the 3 timed steps): "
