@@ -457,3 +457,27 @@ def test_full_size_kmeans_is_independent_of_the_acceleration(be, monkeypatch):
     assert torch.equal(ca.view(torch.int32), cb.view(torch.int32))
     assert oa == ob and sa == sb
     assert all(later <= earlier * (1 + 1e-6) for earlier, later in zip(oa[1:], oa[2:]))   # (iteration 1 may repair empties)
+
+
+@pytest.mark.parametrize("env", [{"AT_FILTER_SCREEN": "0"}, {"AT_FILTER_FUSED": "0"}, {"AT_FILTER_NB": "4"},
+                                 {"AT_FILTER_NB": "2", "AT_FILTER_WPS2": "1"}, {"AT_DMIN_KERNEL": "0"},
+                                 {"AT_C2F_FUSED": "0"}, {"AT_FILTER": "0", "AT_PRUNE_NB": "1"}])
+def test_ab_switches_leave_the_bits_alone(be, oracle, monkeypatch, env):
+    """Every A/B switch of README.md selects another route to the same ids and distances."""
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    rng = np.random.default_rng(5)
+    n, d, k = 70000, 64, 2048
+    centers = _unit_rows(rng, k, d, oracle)
+    x = oracle.l2norm_rows((centers[rng.integers(0, k, n)] + 0.05 * rng.standard_normal((n, d))).astype(np.float32))
+    c = oracle.l2norm_rows((centers + 0.01 * rng.standard_normal((k, d))).astype(np.float32))
+    c[1000:1010] = c[0:10]
+    ids_o, dis_o = oracle.assign(x, c)
+    xt, ct = be._f32(x), be._f32(c)
+    cperm = be.from_host(be.group_rows_kd(c))
+    dmin = be.group_min_dist(ct, cperm)
+    guess = torch.from_numpy(np.where(rng.random(n) < 0.8, ids_o, rng.integers(0, k, n))).to(be.device)
+    ids, dis = be.assign_pruned(xt, ct, be.visit_order(guess.contiguous(), None, k), cperm, dmin)
+    assert np.array_equal(ids.cpu().numpy(), ids_o) and np.array_equal(bits(dis.cpu().numpy()), bits(dis_o))
+    ids, dis = be.assign_c2f(xt, ct, cperm, dmin, coherent=True)
+    assert np.array_equal(ids.cpu().numpy(), ids_o) and np.array_equal(bits(dis.cpu().numpy()), bits(dis_o))
