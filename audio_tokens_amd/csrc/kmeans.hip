@@ -22,6 +22,11 @@
 
 #include "at_internal.h"
 
+// Onesweep radix sort at every size: below a million items rocPRIM would switch to a merge sort of ~18
+// small launches, which is what an iteration of a sharded (N-GPU) run would then mostly consist of;
+// the keys here are 13-21 bits wide, two or three onesweep passes.
+using at_radix_config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
+
 namespace {
 
 constexpr int WG = 256;
@@ -382,10 +387,10 @@ int at_centroid_accum_f32(at_ctx* ctx, const float* x, int64_t n, int d, const i
         rocprim::double_buffer<uint32_t> kb(keys_a, keys_b);
         rocprim::double_buffer<uint32_t> vb(vals_a, vals_b);
         size_t tmp_bytes = 0;
-        AT_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kb, vb, (size_t)n, 0, bits, stream));
+        AT_HIP(rocprim::radix_sort_pairs<at_radix_config>(nullptr, tmp_bytes, kb, vb, (size_t)n, 0, bits, stream));
         void* tmp = at_ws(ctx, WS_SORT_TMP, tmp_bytes, stream);
         if (!tmp) return AT_E_NOMEM;
-        AT_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, kb, vb, (size_t)n, 0, bits, stream));
+        AT_HIP(rocprim::radix_sort_pairs<at_radix_config>(tmp, tmp_bytes, kb, vb, (size_t)n, 0, bits, stream));
         order = vb.current();
         sorted_keys = kb.current();
     }

@@ -24,6 +24,11 @@
 
 #include "at_internal.h"
 
+// Onesweep radix sort at every size: below a million items rocPRIM would switch to a merge sort of ~18
+// small launches, which is what an iteration of a sharded (N-GPU) run would then mostly consist of;
+// the keys here are 13-21 bits wide, two or three onesweep passes.
+using at_radix_config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
+
 namespace {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -357,10 +362,10 @@ int at_visit_order_f32(at_ctx* ctx, const int64_t* ids, const float* dis, int64_
     rocprim::double_buffer<uint32_t> kb(keys_a, keys_b);
     rocprim::double_buffer<uint32_t> vb(vals_a, vals_b);
     size_t tmp_bytes = 0;
-    AT_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kb, vb, (size_t)n, 0, bits, stream));
+    AT_HIP(rocprim::radix_sort_pairs<at_radix_config>(nullptr, tmp_bytes, kb, vb, (size_t)n, 0, bits, stream));
     void* tmp = at_ws(ctx, WS_VISIT_TMP, tmp_bytes, stream);
     if (!tmp) return AT_E_NOMEM;
-    AT_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, kb, vb, (size_t)n, 0, bits, stream));
+    AT_HIP(rocprim::radix_sort_pairs<at_radix_config>(tmp, tmp_bytes, kb, vb, (size_t)n, 0, bits, stream));
     AT_HIP(hipMemcpyAsync(order_out, vb.current(), sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream));
     hipLaunchKernelGGL(key_to_hint_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, stream, kb.current(),
                        (long)n, hint_sorted_out);
