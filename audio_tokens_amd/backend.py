@@ -137,6 +137,12 @@ class HipBackend(HostHelpers):
     def synchronize(self) -> None:
         torch.cuda.current_stream(self.device).synchronize()
 
+    def record_event(self):
+        """Event on the current stream; `.synchronize()` on it waits for the work queued so far only."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return ev
+
     # -- operators ---------------------------------------------------------------------------
     def logmel(self, wave, sample_rate=22050, n_fft=512, hop=128, n_mels=64, fb=None,
                frame_major=False, l2norm=False, out=None) -> torch.Tensor:

@@ -299,7 +299,7 @@ class Kmeans:
         # relies on is computed once per train() -- it only affects how much gets skipped.
         prune = (self.prune and hasattr(be, "assign_pruned") and d in (64, 128) and k >= 1024
                  and (k + 31) // 32 <= 512 and xs.shape[0] >= 4096)
-        ids = dis = order = vorder = None
+        ids = dis = order = vorder = ahead_dmin = None
         if prune:  # grouping from the initial centroids, kept for the whole train()
             cperm = be.from_host(be.group_rows_kd(be.to_host(cent)))
             gnbr = None
@@ -307,9 +307,12 @@ class Kmeans:
             ts = time.time()
             tp = time.perf_counter()
             if prune:
-                if it == 2 and init_centroids is None:  # cold start: regroup once the centroids have settled
+                regroup = it == 2 and init_centroids is None
+                if regroup:  # cold start: regroup once the centroids have settled
                     cperm = be.from_host(be.group_rows_kd(be.to_host(cent)))
-                dmin = be.group_min_dist(cent, cperm)
+                # (bounds of these very centroids and grouping may already be queued: see below)
+                dmin = ahead_dmin if (ahead_dmin is not None and not regroup) else be.group_min_dist(cent, cperm)
+                ahead_dmin = None
                 if ids is None:   # no previous assignment yet: coarse-to-fine exact search
                     gnbr = be.group_neighbours(be.group_means(cent, cperm), 8)
                     ids, dis = be.assign_c2f(xs, cent, cperm, dmin, gnbr)
@@ -335,7 +338,13 @@ class Kmeans:
             cent, hassign = be.centroid_finalize(parts, k, d)
             hassign_host.copy_(hassign, non_blocking=True)
             obj_host.copy_(obj, non_blocking=True)
-            be.synchronize()
+            # the next iteration's centroid-to-group bounds are queued before the host waits for the counts
+            # (they stand unless a cluster came out empty and split_clusters moves centroids): the device
+            # works through the host round trip, which matters once an iteration is a fraction of a ms
+            counts_ready = be.record_event()
+            if prune and it + 1 < self.niter and not (it + 1 == 2 and init_centroids is None):
+                ahead_dmin = be.group_min_dist(cent, cperm)
+            counts_ready.synchronize()        # (only the read-backs: the bounds kernel keeps running)
             tp = lap("exchange+finalize+readback", tp)
             t_search += time.time() - ts  # (the whole iteration is device work here)
             h = hassign_host.numpy()
@@ -347,6 +356,8 @@ class Kmeans:
                 h_work = h.copy()
                 nsplit = be.split_clusters(h_work, c_host, ns)
                 cent = be.from_host(c_host)
+                if nsplit:
+                    ahead_dmin = None   # those bounds were of centroids that have just moved
             tp = lap("split", tp)
             st = dict(obj=float(np.float32(obj_host.item())), time=time.time() - t0, time_search=t_search,
                       imbalance_factor=imbalance, nsplit=nsplit)

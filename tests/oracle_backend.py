@@ -41,6 +41,12 @@ class OracleBackend(HostHelpers):
     def synchronize(self):
         pass
 
+    def record_event(self):
+        class _Done:
+            def synchronize(self):
+                pass
+        return _Done()
+
     def resample(self, wave, orig_freq, new_freq):
         w = self._f32(wave)
         if w.dim() == 1:
