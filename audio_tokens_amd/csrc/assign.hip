@@ -1282,6 +1282,8 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
         // Stage 1: fp16-split filter (filter.hip) names the winner of every row whose runner-up is
         // provably out of reach and lists the others; stage 2 below redoes the listed rows with the
         // fp32 sweep.  Coarse mode (guesses only) needs neither the list nor stage 2.
+        int rcp = at_filter_resolve_pending(ctx);   // statistics (and the list-length verdict) of the previous call
+        if (rcp) return rcp;
         unsigned* misc = static_cast<unsigned*>(at_ws(ctx, WS_FILTER_MISC, 256, stream));
         uint32_t* list = static_cast<uint32_t*>(at_ws(ctx, WS_FILTER_LIST, sizeof(uint32_t) * 5 * ((size_t)n + 64), stream));
         if (!misc || !list) return AT_E_NOMEM;
@@ -1298,6 +1300,29 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
             if (rc) return rc;
         }  // (guess generators wrote an approximate distance themselves: it only orders the next visit)
         if (mode != 0) return AT_OK;
+        // The list of rows to redo is normally short.  Asynchronous form: the redo kernel reads the list
+        // length on the device, the statistics words go to pinned memory and are folded in at the next
+        // call or query -- no host round trip here.  A call that turns out to have listed more than
+        // n/16 rows (badly scaled data) was still answered correctly (the redo strides over any length),
+        // but switches this context to the synchronous form below, whose redo of long lists is the
+        // fp32 MFMA sweep.
+        const char* sy = std::getenv("AT_FILTER_SYNC");  // A/B aid: 1 = always the synchronous form
+        if (!ctx->filter_force_sync && !(sy && std::atoi(sy) == 1)) {
+            if (!ctx->filter_host_misc) {
+                AT_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->filter_host_misc), 64 * sizeof(unsigned), hipHostMallocDefault));
+                AT_HIP(hipEventCreateWithFlags(&ctx->filter_copied, hipEventDisableTiming));
+            }
+            int64_t wgs = n / 64;                      // enough workgroups for a list of 1.5 % of the rows in one go
+            if (wgs < 256) wgs = 256;
+            if (wgs > 65535) wgs = 65535;
+            rc = at_filter_redo_rows(ctx, x, D, c, k, list, wgs, order, cperm, dmin, ng, misc, aux, ids, dist, misc + 1, stream);
+            if (rc) return rc;
+            AT_HIP(hipMemcpyAsync(ctx->filter_host_misc, misc, 64 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+            AT_HIP(hipEventRecord(ctx->filter_copied, stream));
+            ctx->filter_pending = 1;
+            ctx->filter_pending_rows = n;
+            return AT_OK;
+        }
         unsigned host_misc[64];
         AT_HIP(hipMemcpyAsync(host_misc, misc, sizeof host_misc, hipMemcpyDeviceToHost, stream));
         AT_HIP(hipStreamSynchronize(stream));
@@ -1313,11 +1338,12 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
             ctx->filter_ms += ms;
             ctx->filter_launches++;
         }
+        if ((int64_t)listed * 16 <= n) ctx->filter_force_sync = 0;   // the data behave again
         if (listed == 0) return AT_OK;
         // short lists: one workgroup per row on the vector ALU; long ones (badly conditioned data,
         // centroids outside the fp16 range): the fp32 MFMA sweep over the listed rows
         if ((int64_t)listed * 16 <= n)
-            return at_filter_redo_rows(ctx, x, D, c, k, list, listed, order, cperm, dmin, ng, misc, aux, ids, dist, stream);
+            return at_filter_redo_rows(ctx, x, D, c, k, list, listed, order, cperm, dmin, ng, misc, aux, ids, dist, nullptr, stream);
         rc = prep_fp32_image();
         if (rc) return rc;
         n2 = listed < 64 ? 64 : (int64_t)listed;
@@ -1391,9 +1417,35 @@ extern "C" int at_prune_mask_f32(at_ctx* ctx, const float* x, int64_t n, int d, 
 }
 
 // fp16-split filter: rows swept / rows handed to the fp32 redo since the last reset.
+// Folds the statistics words an asynchronous exact call left in pinned memory into the totals.
+int at_filter_resolve_pending(at_ctx* ctx) {
+    if (!ctx->filter_pending) return AT_OK;
+    AT_HIP(hipEventSynchronize(ctx->filter_copied));
+    const unsigned* hm = ctx->filter_host_misc;
+    const unsigned listed = hm[1];
+    ctx->filter_rows += ctx->filter_pending_rows;
+    ctx->filter_listed += listed;
+    for (int i = 0; i < 16; i++) {
+        ctx->filter_tiles += hm[4 + 2 * i];
+        ctx->filter_refined += hm[5 + 2 * i];
+    }
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, ctx->filter_ev[0], ctx->filter_ev[1]) == hipSuccess) {
+        ctx->filter_ms += ms;
+        ctx->filter_launches++;
+    }
+    if ((int64_t)listed * 16 > ctx->filter_pending_rows) ctx->filter_force_sync = 1;
+    ctx->filter_pending = 0;
+    return AT_OK;
+}
+
 extern "C" int at_filter_stats(at_ctx* ctx, int64_t* rows, int64_t* listed, double* sweep_ms, int64_t* sweeps,
                                int64_t* tiles, int64_t* refined, int reset) {
     AT_REQUIRE(ctx && rows && listed, "at_filter_stats: bad arguments");
+    {
+        int rcp = at_filter_resolve_pending(ctx);
+        if (rcp) return rcp;
+    }
     *rows = ctx->filter_rows;
     *listed = ctx->filter_listed;
     if (sweep_ms) *sweep_ms = ctx->filter_ms;

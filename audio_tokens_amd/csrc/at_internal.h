@@ -48,7 +48,15 @@ struct at_ctx {
     hipEvent_t filter_ev[2];             // around the stage-1 kernel of exact calls (created on first use)
     double filter_ms;                    // summed stage-1 kernel time, over filter_launches launches
     int64_t filter_launches;
-    int64_t filter_tiles, filter_refined;  // 32x32 tiles multiplied (hi*hi) / refined (lo products too), exact calls
+    int64_t filter_tiles, filter_refined;
+    // asynchronous exact calls: the statistics words of the last call are copied to pinned memory and folded
+    // into the totals at the next call / query; a call whose list was long switches the context to the
+    // synchronous form (with its fp32 MFMA redo) from then on
+    unsigned* filter_host_misc;          // pinned, 64 words
+    hipEvent_t filter_copied;
+    int filter_pending, filter_force_sync;
+    int64_t filter_pending_rows;
+  // 32x32 tiles multiplied (hi*hi) / refined (lo products too), exact calls
     hipStream_t side_stream;             // centroid_accum: long member lists beside the short ones
     hipEvent_t side_ev[2];
     int defer_join, join_pending;        // at_centroid_accum_defer / at_centroid_accum_join
@@ -102,12 +110,14 @@ int at_filter_gather_ambiguous(at_ctx* ctx, uint32_t* amb_list, uint32_t* amb_so
 
 int at_filter_redo_rows(at_ctx* ctx, const float* x, int d, const float* c, int k, const uint32_t* list, int64_t m,
                         const uint32_t* order, const int32_t* cperm, const float* dmin, int ng, const unsigned* misc,
-                        const uint32_t* aux, int64_t* ids, float* dist, hipStream_t stream);
+                        const uint32_t* aux, int64_t* ids, float* dist, const unsigned* count_dev, hipStream_t stream);
 
 int at_group_min_dist_f16(at_ctx* ctx, const float* c, int k, int d, const int32_t* cperm, int ng, float* dmin,
                           hipStream_t stream);
 
 int at_filter_coarse(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k, const int32_t* cperm, int ng,
                      const float* means, const uint32_t* gnbr, int64_t* ids, float* dist, hipStream_t stream);
+
+int at_filter_resolve_pending(at_ctx* ctx);
 
 static inline bool at_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

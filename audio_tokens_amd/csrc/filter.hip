@@ -808,13 +808,17 @@ __global__ void __launch_bounds__(WG) exact_rows_kernel(const float* __restrict_
                                                         const float* __restrict__ dmin, int ng,
                                                         const unsigned* __restrict__ misc,
                                                         const uint32_t* __restrict__ aux, long* __restrict__ ids,
-                                                        float* __restrict__ dist) {
+                                                        float* __restrict__ dist, const unsigned* __restrict__ count_dev) {
     __shared__ int needed[512];
     __shared__ int n_needed;
     __shared__ float red_d[WG / 64];
     __shared__ unsigned red_i[WG / 64];
     const int tid = threadIdx.x;
-    const long row = order[list[blockIdx.x]];
+    // entry = blockIdx.x; with count_dev the list length is read on the device and the grid strides
+    // over it (the launch then needs no host round trip; blocks beyond the list leave at once)
+    const unsigned count = count_dev ? *count_dev : gridDim.x;
+    for (unsigned entry = blockIdx.x; entry < count; entry += gridDim.x) {
+    const long row = order[list[entry]];
     const long p = ids[row];
     const bool has = p >= 0 && p < k;
     f32x4 xv[D / 4];
@@ -840,7 +844,7 @@ __global__ void __launch_bounds__(WG) exact_rows_kernel(const float* __restrict_
         }
         return __builtin_fmaxf(__builtin_fmaf(-2.0f, ip, xn + cn), 0.0f);
     };
-    const uint32_t second = aux ? aux[blockIdx.x] : NONE;
+    const uint32_t second = aux ? aux[entry] : NONE;
     if (has && second < (uint32_t)k) {  // the filter left exactly two candidates: score both, lowest index on a tie
         if (tid == 0) {
             const float d1 = contract_dist(p), d2 = contract_dist((long)second);
@@ -848,7 +852,7 @@ __global__ void __launch_bounds__(WG) exact_rows_kernel(const float* __restrict_
             ids[row] = take2 ? (long)second : p;
             if (dist) dist[row] = take2 ? d2 : d1;
         }
-        return;
+        continue;
     }
     float tau = __builtin_inff();
     if (has) {
@@ -900,6 +904,8 @@ __global__ void __launch_bounds__(WG) exact_rows_kernel(const float* __restrict_
         ids[row] = bi == NONE ? -1L : (long)bi;
         if (dist) dist[row] = bd;
     }
+    __syncthreads();  // the shared scratch is reused by the next entry
+    }  // entry
 }
 
 // dmin[p][g] = a lower bound of min over the members m of group g of |c_p - c_m| (prune.hip uses it in
@@ -1141,22 +1147,20 @@ int at_filter_gather_ambiguous(at_ctx* ctx, uint32_t* amb_list, uint32_t* amb_so
 // Stage 2 for short lists: one workgroup per listed row (see exact_rows_kernel).
 int at_filter_redo_rows(at_ctx* ctx, const float* x, int d, const float* c, int k, const uint32_t* list, int64_t m,
                         const uint32_t* order, const int32_t* cperm, const float* dmin, int ng, const unsigned* misc,
-                        const uint32_t* aux, int64_t* ids, float* dist, hipStream_t stream) {
+                        const uint32_t* aux, int64_t* ids, float* dist, const unsigned* count_dev, hipStream_t stream) {
     (void)ctx;
-    if (m <= 0) return AT_OK;
+    if (m <= 0) return AT_OK;   // m = list length, or (with count_dev) the number of workgroups to launch
     AT_REQUIRE(ng <= 512, "at_filter_redo_rows: ng > 512");
     if (d == 64)
         hipLaunchKernelGGL(exact_rows_kernel<64>, dim3((unsigned)m), dim3(WG), 0, stream, x, c, k, list, order, cperm, dmin,
-                           ng, misc, aux, reinterpret_cast<long*>(ids), dist);
+                           ng, misc, aux, reinterpret_cast<long*>(ids), dist, count_dev);
     else
         hipLaunchKernelGGL(exact_rows_kernel<128>, dim3((unsigned)m), dim3(WG), 0, stream, x, c, k, list, order, cperm,
-                           dmin, ng, misc, aux, reinterpret_cast<long*>(ids), dist);
+                           dmin, ng, misc, aux, reinterpret_cast<long*>(ids), dist, count_dev);
     AT_LAUNCH_CHECK();
     return AT_OK;
 }
 
-// at_group_min_dist_f32 through the matrix cores (d = 64 / 128): builds the fp16 image of the grouped
-// centroids (the sweep rebuilds it anyway) and bounds every centroid-to-group distance from below.
 int at_group_min_dist_f16(at_ctx* ctx, const float* c, int k, int d, const int32_t* cperm, int ng, float* dmin,
                           hipStream_t stream) {
     unsigned char* img = static_cast<unsigned char*>(at_ws(ctx, WS_CENT_IMG16, group_bytes(d) * (size_t)ng, stream));

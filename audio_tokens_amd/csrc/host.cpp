@@ -66,6 +66,8 @@ void at_destroy(at_ctx* ctx) {
         if (ctx->side_ev[i]) (void)hipEventDestroy(ctx->side_ev[i]);
     }
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    if (ctx->filter_copied) (void)hipEventDestroy(ctx->filter_copied);
+    if (ctx->filter_host_misc) (void)hipHostFree(ctx->filter_host_misc);
     (void)hipSetDevice(prev);
     delete ctx;
 }

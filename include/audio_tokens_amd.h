@@ -169,9 +169,9 @@ int at_prune_mask_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float
 /* The exact sweeps above accept mode | 2: stage 1 is then the fp16-split filter
  * (csrc/filter.hip: three fp16 MFMAs per fp32 one, winner accepted only when the runner-up is
  * provably out of reach of the fp32 contract), the remaining rows are redone by the fp32 sweep, so
- * ids/dist are bit-identical to mode without the flag.  prepass_done | 2 tells the call that the fp16 image
- * at_group_min_dist_f32 built is still current (same c, cperm; centroids unchanged since), so it is reused.  With the flag the call synchronises the
- * stream once (it reads the number of rows to redo).  at_filter_stats reports rows swept / redone
+ * ids/dist are bit-identical to mode without the flag, and the call is asynchronous (the redo kernel reads the
+ * list length on the device) unless a previous call on this context listed more than n/16 rows.  prepass_done | 2 tells the call that the fp16 image
+ * at_group_min_dist_f32 built is still current (same c, cperm; centroids unchanged since), so it is reused.  at_filter_stats reports rows swept / redone
  * the summed HIP-event time of the stage-1 kernel over `sweeps` exact calls, and how many 32x32
  * tiles it multiplied (hi*hi: d/16 MFMAs) / refined (2 d/16 more) (NULL to skip any of them);
  * at_filter_probe_f32 is a test hook (stage 1 only; approx[2i], approx[2i+1] = approximate

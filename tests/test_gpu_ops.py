@@ -461,7 +461,7 @@ def test_full_size_kmeans_is_independent_of_the_acceleration(be, monkeypatch):
 
 @pytest.mark.parametrize("env", [{"AT_FILTER_SCREEN": "0"}, {"AT_FILTER_FUSED": "0"}, {"AT_FILTER_NB": "4"},
                                  {"AT_FILTER_NB": "2", "AT_FILTER_WPS2": "1"}, {"AT_DMIN_KERNEL": "0"},
-                                 {"AT_C2F_FUSED": "0"}, {"AT_FILTER": "0", "AT_PRUNE_NB": "1"}])
+                                 {"AT_C2F_FUSED": "0"}, {"AT_FILTER": "0", "AT_PRUNE_NB": "1"}, {"AT_FILTER_SYNC": "1"}])
 def test_ab_switches_leave_the_bits_alone(be, oracle, monkeypatch, env):
     """Every A/B switch of README.md selects another route to the same ids and distances."""
     for key, val in env.items():
