@@ -47,6 +47,7 @@ SIGNATURES = {
     "at_filter_probe_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp,
                                    _c.POINTER(_i64), _vp]),
     "at_group_means_f32": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
+    "at_group_neighbours_f32": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "at_assign_pruned_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     "at_prune_mask_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp]),
     "at_gather_rows_f32": (_i32, [_vp, _vp, _i32, _vp, _i64, _vp, _vp]),

@@ -295,18 +295,14 @@ class HipBackend(HostHelpers):
 
     def group_neighbours(self, means, nnb=4) -> torch.Tensor:
         """[ng, ceil(ng/32)] bit table: for every group the nnb groups with the nearest means
-        (itself included).  Heuristic input of the coarse pass; host side, tiny."""
-        m = self.to_host(means).astype(np.float32)
-        ng = m.shape[0]
-        sq = (m * m).sum(1)
-        d2 = sq[:, None] + sq[None, :] - 2.0 * (m @ m.T)
-        np.fill_diagonal(d2, -1.0)                                  # a group is its own first neighbour
-        nb = np.argsort(d2, axis=1, kind="stable")[:, :min(nnb, ng)]
-        ngw = (ng + 31) // 32
-        bits = np.zeros((ng, ngw), np.uint32)
-        rows = np.repeat(np.arange(ng), nb.shape[1])
-        np.bitwise_or.at(bits, (rows, (nb >> 5).ravel()), (np.uint32(1) << (nb & 31).astype(np.uint32)).ravel())
-        return self.from_host(bits.view(np.int32))
+        (itself included).  Heuristic input of the coarse pass."""
+        means = self._f32(means)
+        ng, d = means.shape
+        gnbr = torch.empty((ng, (ng + 31) // 32), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_group_neighbours_f32(self.ctx.handle, _ptr(means), ng, d, int(nnb), _ptr(gnbr),
+                                                        self._stream()))
+        return gnbr
 
     def _nearest_mean(self, x, means):
         """Group of the (approximately) nearest group mean -- a guess, so at d = 64 it is taken from the

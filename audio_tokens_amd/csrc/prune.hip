@@ -260,6 +260,55 @@ __global__ void __launch_bounds__(WG) group_means_kernel(const float* __restrict
     }
 }
 
+// Neighbour table of the groups (heuristic input of the guess generators): one workgroup per group g
+// scores every group mean against mean g (fp32 sum of squared differences), then takes the nnb nearest
+// (g itself first; ties to the lower index) and sets their bits in gnbr[g][0..ngw).
+__global__ __launch_bounds__(256) void group_neighbours_kernel(const float* __restrict__ means, int ng, int d, int nnb,
+                                                               uint32_t* __restrict__ gnbr) {
+    __shared__ float own[128];
+    __shared__ unsigned long long wave_best[4];
+    __shared__ uint32_t bits[16];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int ngw = (ng + 31) / 32;
+    for (int f = tid; f < d; f += 256) own[f] = means[(size_t)g * d + f];
+    if (tid < 16) bits[tid] = 0u;
+    __syncthreads();
+    // up to two candidates per thread (ng <= 512); key = distance bits (>= 0, so they order as integers) : index
+    unsigned long long key[2];
+    for (int s = 0; s < 2; s++) {
+        const int j = tid + 256 * s;
+        key[s] = ~0ull;
+        if (j < ng && j != g) {
+            float acc = 0.0f;
+            for (int f = 0; f < d; f++) {
+                const float t = means[(size_t)j * d + f] - own[f];
+                acc = __builtin_fmaf(t, t, acc);
+            }
+            key[s] = ((unsigned long long)__float_as_uint(acc) << 32) | (unsigned)j;
+        }
+    }
+    if (tid == 0) bits[g >> 5] |= 1u << (g & 31);
+    for (int round = 1; round < nnb && round < ng; round++) {
+        unsigned long long best = key[0] < key[1] ? key[0] : key[1];
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(best, o, 64);
+            best = other < best ? other : best;
+        }
+        if ((tid & 63) == 0) wave_best[tid >> 6] = best;
+        __syncthreads();
+        best = wave_best[0];
+        for (int w = 1; w < 4; w++) best = wave_best[w] < best ? wave_best[w] : best;
+        __syncthreads();
+        if (best == ~0ull) break;
+        const unsigned j = (unsigned)best;
+        if (tid == 0) bits[j >> 5] |= 1u << (j & 31);
+        if (key[0] == best) key[0] = ~0ull;
+        if (key[1] == best) key[1] = ~0ull;
+    }
+    __syncthreads();
+    if (tid < ngw) gnbr[(size_t)g * ngw + tid] = bits[tid];
+}
+
 }  // namespace
 
 // ---- entry points used by assign.hip and the C ABI -------------------------------------------
@@ -337,6 +386,16 @@ int at_group_means_f32(at_ctx* ctx, const float* c, int k, int d, const int32_t*
     AT_REQUIRE(ctx && c && cperm && means && k > 0 && d > 0 && ng > 0, "at_group_means_f32: bad arguments");
     AT_HIP(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(group_means_kernel, dim3(ng), dim3(WG), 0, stream, c, d, cperm, means);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}
+
+int at_group_neighbours_f32(at_ctx* ctx, const float* means, int ng, int d, int nnb, uint32_t* gnbr, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AT_REQUIRE(ctx && means && gnbr, "at_group_neighbours_f32: null pointer");
+    AT_REQUIRE(ng > 0 && ng <= 512 && d > 0 && d <= 128 && nnb > 0, "at_group_neighbours_f32: needs ng <= 512, d <= 128, nnb > 0");
+    AT_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(group_neighbours_kernel, dim3(ng), dim3(256), 0, stream, means, ng, d, nnb, gnbr);
     AT_LAUNCH_CHECK();
     return AT_OK;
 }

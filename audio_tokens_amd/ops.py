@@ -304,16 +304,29 @@ class Kmeans:
         # rows by distance buys nothing: the member-list order of the accumulation doubles as the visiting
         # order and the second sort of the iteration is dropped.
         member_order = prune and xs.shape[0] < 96 * k   # (measured: -8 % per iteration at 32 rows per cluster)
-        if prune:  # grouping from the initial centroids, kept for the whole train()
-            cperm = be.from_host(be.group_rows_kd(be.to_host(cent)))
+        regrouping = None   # host grouping of newer centroids, under way on the helper thread
+        if prune:
+            # The spatial grouping only decides how much the exact sweep can skip.  A warm start begins with
+            # the grouping the previous train() ended with while the host regroups the new initial centroids
+            # beside the first iterations; a cold start groups its initial centroids before it can begin.
+            cached = getattr(self, "_cperm_cache", None)
+            if init_centroids is not None and cached is not None and cached[0] == (k, d):
+                cperm = cached[1]
+                regrouping = _grouper().submit(be.group_rows_kd, be.to_host(cent))
+            else:
+                cperm = be.from_host(be.group_rows_kd(be.to_host(cent)))
             gnbr = None
         for it in range(self.niter):
             ts = time.time()
             tp = time.perf_counter()
             if prune:
-                regroup = it == 2 and init_centroids is None
-                if regroup:  # cold start: regroup once the centroids have settled
-                    cperm = be.from_host(be.group_rows_kd(be.to_host(cent)))
+                regroup = regrouping is not None and regrouping.done()
+                if regroup:
+                    cperm = be.from_host(regrouping.result())
+                    regrouping = None
+                elif it == 2 and init_centroids is None and regrouping is None:
+                    # cold start: regroup once the centroids have settled (taken up when the host is done)
+                    regrouping = _grouper().submit(be.group_rows_kd, be.to_host(cent))
                 # (bounds of these very centroids and grouping may already be queued: see below)
                 dmin = ahead_dmin if (ahead_dmin is not None and not regroup) else be.group_min_dist(cent, cperm)
                 ahead_dmin = None
@@ -349,7 +362,7 @@ class Kmeans:
             # (they stand unless a cluster came out empty and split_clusters moves centroids): the device
             # works through the host round trip, which matters once an iteration is a fraction of a ms
             counts_ready = be.record_event()
-            if prune and it + 1 < self.niter and not (it + 1 == 2 and init_centroids is None):
+            if prune and it + 1 < self.niter:
                 ahead_dmin = be.group_min_dist(cent, cperm)
             counts_ready.synchronize()        # (only the read-backs: the bounds kernel keeps running)
             tp = lap("exchange+finalize+readback", tp)
@@ -373,6 +386,10 @@ class Kmeans:
                 print(f"  Iteration {it} ({st['time']:.2f} s, search {st['time_search']:.2f} s): "
                       f"objective={st['obj']:g} imbalance={imbalance:.3f} nsplit={nsplit}", flush=True)
         self._last_assign = ids
+        if prune:
+            if regrouping is not None and regrouping.done():
+                cperm = be.from_host(regrouping.result())
+            self._cperm_cache = ((k, d), cperm)
         return self._finish(cent)
 
     def _finish(self, cent):
@@ -382,6 +399,18 @@ class Kmeans:
         self.index = IndexFlatL2(self.d, backend=self.backend)
         self.index.add(cent)
         return float(self.obj[-1]) if self.obj.size else 0.0
+
+
+_GROUPER = None
+
+
+def _grouper():
+    """One helper thread for the host-side spatial grouping (a C call that releases the GIL)."""
+    global _GROUPER
+    if _GROUPER is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _GROUPER = ThreadPoolExecutor(max_workers=1, thread_name_prefix="at-grouping")
+    return _GROUPER
 
 
 class IndexFlatL2:

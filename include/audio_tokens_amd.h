@@ -137,6 +137,8 @@ int at_assign_hinted_f32(at_ctx* ctx, const float* x, int64_t n, int d, const fl
  * at_visit_order_f32: rows sorted by (previous id, previous distance): order_out and the ids in
  *   that order (both DEVICE uint32 [n]).
  * at_group_means_f32: means[g] (DEVICE float [ng][d]) = mean row of group g.
+ * at_group_neighbours_f32: gnbr[g] (DEVICE uint32 [ng][ceil(ng/32)]) = bit set of the nnb groups whose
+ *   means are nearest to mean g, g itself included (ng <= 512, d <= 128); input of the guess generators.
  * at_assign_pruned_f32, mode 0: the answer of at_assign_f32, bit for bit (d = 64 or 128, n >= 20,
  *   ng <= 512).  Every row's guess hint_sorted[p] (for row order[p]) is scored exactly first; a
  *   32-centroid group is then skipped for a 32-row tile when the triangle inequality, with a margin
@@ -155,6 +157,8 @@ int at_visit_order_f32(at_ctx* ctx, const int64_t* ids, const float* dis_or_null
                        uint32_t* order_out, uint32_t* hint_sorted_out, void* stream);
 int at_group_means_f32(at_ctx* ctx, const float* c, int k, int d, const int32_t* cperm, int ng,
                        float* means, void* stream);
+int at_group_neighbours_f32(at_ctx* ctx, const float* means, int ng, int d, int nnb, uint32_t* gnbr,
+                            void* stream);
 int at_assign_pruned_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
                          const uint32_t* order, const uint32_t* hint_sorted, const int32_t* cperm,
                          int ng, const float* dmin_or_null, int mode, int prepass_done, int64_t* ids,

@@ -481,3 +481,21 @@ def test_ab_switches_leave_the_bits_alone(be, oracle, monkeypatch, env):
     assert np.array_equal(ids.cpu().numpy(), ids_o) and np.array_equal(bits(dis.cpu().numpy()), bits(dis_o))
     ids, dis = be.assign_c2f(xt, ct, cperm, dmin, coherent=True)
     assert np.array_equal(ids.cpu().numpy(), ids_o) and np.array_equal(bits(dis.cpu().numpy()), bits(dis_o))
+
+
+@pytest.mark.parametrize("ng,d,nnb", [(256, 64, 8), (256, 64, 4), (37, 128, 4), (3, 64, 8), (512, 64, 8)])
+def test_group_neighbours_names_the_nearest_means(be, ng, d, nnb):
+    """The neighbour table (a heuristic input, it never decides a result) names g itself and the groups
+    whose means are nearest to it."""
+    rng = np.random.default_rng(ng + nnb)
+    m = rng.standard_normal((ng, d)).astype(np.float32)
+    m[1] = m[0]                                                     # a tie: the lower index first
+    bits_dev = be.group_neighbours(be.from_host(m), nnb).cpu().numpy().view(np.uint32)
+    assert bits_dev.shape == (ng, (ng + 31) // 32)
+    d2 = ((m[:, None, :].astype(np.float64) - m[None, :, :]) ** 2).sum(-1)
+    for g in range(ng):
+        chosen = [j for j in range(ng) if (bits_dev[g, j >> 5] >> (j & 31)) & 1]
+        assert g in chosen and len(chosen) == min(nnb, ng)
+        others = np.delete(np.arange(ng), g)
+        kth = np.sort(d2[g, others])[min(nnb, ng) - 2] if min(nnb, ng) > 1 else 0.0
+        assert all(j == g or d2[g, j] <= kth * (1 + 1e-5) for j in chosen)

@@ -10,7 +10,8 @@ be = default_backend()
 wave = synth_clips(1300, device="cuda")
 frames = be.logmel(wave, frame_major=True, l2norm=True)
 del wave
-for world in (1, 2, 4, 8):
+worlds = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
+for world in worlds:
     n = 2097152 // world
     x = frames[:n].contiguous()
     km = Kmeans(64, 8192, niter=20, backend=be)
