@@ -59,6 +59,22 @@ class HostHelpers:
         _lib.check(self.lib.at_group_rows_kd_host(_np_ptr(rows), k, d, leaf, _np_ptr(out)))
         return out
 
+    # The grouping never decides a result, so a weak fingerprint of the table is enough to hand the grouping
+    # a Kmeans ended with to the IndexFlatL2 later built from the same centroids (a mismatch costs speed only).
+    @staticmethod
+    def _table_fingerprint(rows: np.ndarray):
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        return rows.shape, int(rows.view(np.uint32).sum(dtype=np.uint64))
+
+    def remember_grouping(self, rows: np.ndarray, cperm) -> None:
+        cache = self.__dict__.setdefault("_groupings", {})
+        if len(cache) >= 4:
+            cache.pop(next(iter(cache)))
+        cache[self._table_fingerprint(rows)] = cperm
+
+    def recall_grouping(self, rows: np.ndarray):
+        return self.__dict__.get("_groupings", {}).get(self._table_fingerprint(rows))
+
     def resample_taps(self, orig_freq: int, new_freq: int):
         """-> (taps float32 [new, 2*width + orig], orig, new, width): torchaudio's sinc_interp_hann kernel."""
         o, nw, w = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)

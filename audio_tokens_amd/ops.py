@@ -316,26 +316,30 @@ class Kmeans:
             else:
                 cperm = be.from_host(be.group_rows_kd(be.to_host(cent)))
             gnbr = None
+        def pruned_assign(it):
+            """Queues iteration `it`'s exact search over the current centroids -> (ids, dis)."""
+            nonlocal cperm, regrouping, ahead_dmin, gnbr
+            regroup = regrouping is not None and regrouping.done()
+            if regroup:
+                cperm = be.from_host(regrouping.result())
+                regrouping = None
+            elif it == 2 and init_centroids is None and regrouping is None:
+                # cold start: regroup once the centroids have settled (taken up when the host is done)
+                regrouping = _grouper().submit(be.group_rows_kd, be.to_host(cent))
+            # (bounds of these very centroids and grouping may already be queued: see below)
+            dmin = ahead_dmin if (ahead_dmin is not None and not regroup) else be.group_min_dist(cent, cperm)
+            ahead_dmin = None
+            if ids is None:   # no previous assignment yet: coarse-to-fine exact search
+                gnbr = be.group_neighbours(be.group_means(cent, cperm), 8)
+                return be.assign_c2f(xs, cent, cperm, dmin, gnbr)
+            return be.assign_pruned(xs, cent, vorder if vorder is not None else be.visit_order(ids, dis, k),
+                                    cperm, dmin, image_current=True)
+
         for it in range(self.niter):
             ts = time.time()
             tp = time.perf_counter()
             if prune:
-                regroup = regrouping is not None and regrouping.done()
-                if regroup:
-                    cperm = be.from_host(regrouping.result())
-                    regrouping = None
-                elif it == 2 and init_centroids is None and regrouping is None:
-                    # cold start: regroup once the centroids have settled (taken up when the host is done)
-                    regrouping = _grouper().submit(be.group_rows_kd, be.to_host(cent))
-                # (bounds of these very centroids and grouping may already be queued: see below)
-                dmin = ahead_dmin if (ahead_dmin is not None and not regroup) else be.group_min_dist(cent, cperm)
-                ahead_dmin = None
-                if ids is None:   # no previous assignment yet: coarse-to-fine exact search
-                    gnbr = be.group_neighbours(be.group_means(cent, cperm), 8)
-                    ids, dis = be.assign_c2f(xs, cent, cperm, dmin, gnbr)
-                else:
-                    ids, dis = be.assign_pruned(xs, cent, vorder if vorder is not None else be.visit_order(ids, dis, k),
-                                                cperm, dmin, image_current=True)
+                ids, dis = pruned_assign(it)
             elif ids is None:
                 ids, dis = be.assign(xs, cent)
             else:  # same answer, guided by the previous assignment and its member-list order
@@ -390,7 +394,21 @@ class Kmeans:
             if regrouping is not None and regrouping.done():
                 cperm = be.from_host(regrouping.result())
             self._cperm_cache = ((k, d), cperm)
-        return self._finish(cent)
+        loss = self._finish(cent)
+        if prune and hasattr(be, "remember_grouping"):
+            be.remember_grouping(self.centroids, cperm)   # for the index a tokeniser builds from these centroids
+        return loss
+
+    def lend_grouping(self, table) -> None:
+        """Offers the spatial grouping this object ended with to an IndexFlatL2 later filled with `table`
+        (e.g. the normalised centroids a tokeniser loads): nearby rows stay nearby, and the grouping only
+        ever decides how much the exact search skips."""
+        cached = getattr(self, "_cperm_cache", None)
+        be = self.backend
+        if cached is not None and hasattr(be, "remember_grouping"):
+            table = be.to_host(table) if isinstance(table, torch.Tensor) else np.asarray(table)
+            if table.shape == cached[0]:
+                be.remember_grouping(table, cached[1])
 
     def _finish(self, cent):
         self.centroids_device = cent
@@ -447,7 +465,10 @@ class IndexFlatL2:
         if (self.prune and hasattr(be, "assign_c2f") and self.d in (64, 128) and k >= 1024
                 and (k + 31) // 32 <= 512 and x.shape[0] >= 65536):
             if self._prune is None:
-                cperm = be.from_host(be.group_rows_kd(be.to_host(c)))
+                c_host = be.to_host(c)
+                cperm = be.recall_grouping(c_host) if hasattr(be, "recall_grouping") else None
+                if cperm is None or cperm.numel() != ((k + 31) // 32) * 32:
+                    cperm = be.from_host(be.group_rows_kd(c_host))
                 # 4 neighbour groups for the one-launch guess generator (measured: 1-4 equal, 8 is 6 % slower)
                 self._prune = (cperm, be.group_min_dist(c, cperm), be.group_neighbours(be.group_means(c, cperm), 4))
             cperm, dmin, gnbr = self._prune

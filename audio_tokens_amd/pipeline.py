@@ -100,6 +100,7 @@ class DevicePipeline:
                 km.train(x, init_centroids=km.centroids_device)
             stats.append(km.iteration_stats)
         centroids = be.l2norm_rows(km.centroids_device)
+        km.lend_grouping(centroids)
         sync(); secs["kmeans"] = time.perf_counter() - t0
 
         t0 = time.perf_counter()
@@ -187,6 +188,7 @@ class DevicePipeline:
             km.train(x) if b == 0 else km.train(x, init_centroids=km.centroids_device)
             stats.append(km.iteration_stats)
         centroids = be.l2norm_rows(km.centroids_device)
+        km.lend_grouping(centroids)
         sync(); secs["logmel+kmeans"] = time.perf_counter() - t0
 
         t0 = time.perf_counter()

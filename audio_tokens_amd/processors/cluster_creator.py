@@ -63,6 +63,7 @@ class ClusterCreator:
 
         centroids = kmeans.centroids
         centroids = self.normalize_vectors(centroids)
+        kmeans.lend_grouping(centroids)   # (a tokeniser in this process starts from this grouping)
         self.logger.info(f"Centroids shape: {centroids.shape}")
         Path(self.config.centroids_path).parent.mkdir(parents=True, exist_ok=True)
         np.save(self.config.centroids_path, centroids)

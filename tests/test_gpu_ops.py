@@ -451,11 +451,13 @@ def test_full_size_kmeans_is_independent_of_the_acceleration(be, monkeypatch):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             km.train(x)
-        runs[label] = (km.centroids_device.clone(), [s["obj"] for s in km.iteration_stats], [s["nsplit"] for s in km.iteration_stats])
+            first = (km.centroids_device.clone(), [s["obj"] for s in km.iteration_stats], [s["nsplit"] for s in km.iteration_stats])
+            km.train(x[:1000000], init_centroids=km.centroids_device)     # warm start: previous grouping, regrouped beside
+        runs[label] = first + (km.centroids_device.clone(), [s["obj"] for s in km.iteration_stats])
     monkeypatch.delenv("AT_FILTER", raising=False)
-    (ca, oa, sa), (cb, ob, sb) = runs["filtered"], runs["fp32"]
-    assert torch.equal(ca.view(torch.int32), cb.view(torch.int32))
-    assert oa == ob and sa == sb
+    (ca, oa, sa, wa, woa), (cb, ob, sb, wb, wob) = runs["filtered"], runs["fp32"]
+    assert torch.equal(ca.view(torch.int32), cb.view(torch.int32)) and torch.equal(wa.view(torch.int32), wb.view(torch.int32))
+    assert oa == ob and sa == sb and woa == wob
     assert all(later <= earlier * (1 + 1e-6) for earlier, later in zip(oa[1:], oa[2:]))   # (iteration 1 may repair empties)
 
 
