@@ -58,7 +58,8 @@ __host__ __device__ constexpr size_t lo_off(int d) { return (size_t)(d / 16) * 1
 // visits and touches the lo fragments of a few.
 __global__ void __launch_bounds__(WG) prep_centroids_f16_kernel(const float* __restrict__ c, int k, int d,
                                                                 const int32_t* __restrict__ cperm,
-                                                                unsigned char* __restrict__ img) {
+                                                                unsigned char* __restrict__ img,
+                                                                unsigned* __restrict__ max_bits) {
     const int g = blockIdx.x;
     unsigned char* out = img + (size_t)g * group_bytes(d);
     _Float16* frag = reinterpret_cast<_Float16*>(out);
@@ -86,17 +87,10 @@ __global__ void __launch_bounds__(WG) prep_centroids_f16_kernel(const float* __r
         }
         cn[i] = nrm;
         idx[i] = (row >= 0 && row < k) ? (unsigned)row : NONE;
+        // max |c|^2 over the table (every row is in exactly one group): non-negative floats (and +inf, NaN
+        // above them) order like their bit patterns
+        if (max_bits && row >= 0 && row < k) atomicMax(max_bits, __float_as_uint(nrm) & 0x7fffffffu);
     }
-}
-
-__global__ void __launch_bounds__(WG) max_sqnorm_bits_kernel(const float* __restrict__ C, int k, int d,
-                                                             unsigned* __restrict__ out_bits) {
-    const int c = blockIdx.x * WG + threadIdx.x;
-    float s = 0.0f;
-    if (c < k)
-        for (int f = 0; f < d; f++) s = __builtin_fmaf(C[(size_t)c * d + f], C[(size_t)c * d + f], s);
-    // non-negative floats (and +inf, NaN above them) order like their bit patterns
-    atomicMax(out_bits, __float_as_uint(s) & 0x7fffffffu);
 }
 
 // One wavefront per workgroup, the structure of assign_mfma_pruned_reg_kernel (assign.hip): the wave
@@ -1046,10 +1040,8 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
         AT_HIP(hipMemsetAsync(misc + 1, 0, 63 * sizeof(unsigned), stream));  // list length, statistics
     } else {
         ctx->img16_c = nullptr;
-        hipLaunchKernelGGL(prep_centroids_f16_kernel, dim3(ng), dim3(WG), 0, stream, c, k, d, cperm, img);
-        AT_LAUNCH_CHECK();
         AT_HIP(hipMemsetAsync(misc, 0, 64 * sizeof(unsigned), stream));  // max|c|^2, list length, statistics
-        hipLaunchKernelGGL(max_sqnorm_bits_kernel, dim3((k + WG - 1) / WG), dim3(WG), 0, stream, c, k, d, misc);
+        hipLaunchKernelGGL(prep_centroids_f16_kernel, dim3(ng), dim3(WG), 0, stream, c, k, d, cperm, img, misc);
         AT_LAUNCH_CHECK();
     }
     float ta = 0.0f, tb = 0.0f, ra = 0.0f, rb = 0.0f;
@@ -1166,10 +1158,8 @@ int at_group_min_dist_f16(at_ctx* ctx, const float* c, int k, int d, const int32
     unsigned char* img = static_cast<unsigned char*>(at_ws(ctx, WS_CENT_IMG16, group_bytes(d) * (size_t)ng, stream));
     unsigned* misc = static_cast<unsigned*>(at_ws(ctx, WS_FILTER_MISC, 256, stream));  // word 0 = max|c|^2, as the sweep wants it
     if (!img || !misc) return AT_E_NOMEM;
-    hipLaunchKernelGGL(prep_centroids_f16_kernel, dim3(ng), dim3(WG), 0, stream, c, k, d, cperm, img);
-    AT_LAUNCH_CHECK();
     AT_HIP(hipMemsetAsync(misc, 0, sizeof(unsigned), stream));
-    hipLaunchKernelGGL(max_sqnorm_bits_kernel, dim3((k + WG - 1) / WG), dim3(WG), 0, stream, c, k, d, misc);
+    hipLaunchKernelGGL(prep_centroids_f16_kernel, dim3(ng), dim3(WG), 0, stream, c, k, d, cperm, img, misc);
     AT_LAUNCH_CHECK();
     ctx->img16_c = c; ctx->img16_cperm = cperm; ctx->img16_k = k; ctx->img16_d = d; ctx->img16_ng = ng;
     ctx->img16_misc = misc;
@@ -1224,11 +1214,10 @@ int at_filter_coarse(at_ctx* ctx, const float* x, int64_t n, int d, const float*
     if (!img || !img_m || !perm_m || !misc) return AT_E_NOMEM;
     ctx->img16_c = nullptr;
     hipLaunchKernelGGL(iota_pad_kernel, dim3((ngm * 32 + WG - 1) / WG), dim3(WG), 0, stream, perm_m, ng, ngm * 32);
-    hipLaunchKernelGGL(prep_centroids_f16_kernel, dim3(ngm), dim3(WG), 0, stream, means, ng, d, perm_m, img_m);
-    hipLaunchKernelGGL(prep_centroids_f16_kernel, dim3(ng), dim3(WG), 0, stream, c, k, d, cperm, img);
-    AT_LAUNCH_CHECK();
     AT_HIP(hipMemsetAsync(misc, 0, 64 * sizeof(unsigned), stream));
-    hipLaunchKernelGGL(max_sqnorm_bits_kernel, dim3((k + WG - 1) / WG), dim3(WG), 0, stream, c, k, d, misc);
+    hipLaunchKernelGGL(prep_centroids_f16_kernel, dim3(ngm), dim3(WG), 0, stream, means, ng, d, perm_m, img_m,
+                       static_cast<unsigned*>(nullptr));
+    hipLaunchKernelGGL(prep_centroids_f16_kernel, dim3(ng), dim3(WG), 0, stream, c, k, d, cperm, img, misc);
     AT_LAUNCH_CHECK();
     float ta = 0.0f, tb = 0.0f, ra = 0.0f, rb = 0.0f;
     filter_tau(d, &ta, &tb);
