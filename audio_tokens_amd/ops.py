@@ -312,10 +312,16 @@ class Kmeans:
             cached = getattr(self, "_cperm_cache", None)
             if init_centroids is not None and cached is not None and cached[0] == (k, d):
                 cperm = cached[1]
-                regrouping = _grouper().submit(be.group_rows_kd, be.to_host(cent))
+                # (continuing from this object's own result: that grouping is of centroids a few iterations
+                # older than these, nothing to redo)
+                if not (init_centroids is getattr(self, "centroids_device", None)
+                        or init_centroids is getattr(self, "centroids", None)):
+                    regrouping = _grouper().submit(be.group_rows_kd, be.to_host(cent))
             else:
                 cperm = be.from_host(be.group_rows_kd(be.to_host(cent)))
             gnbr = None
+        # a last regrouping near the end: the next warm start and the tokeniser's index begin with it
+        late_regroup = self.niter - 6 if self.niter >= 10 else -1
         def pruned_assign(it):
             """Queues iteration `it`'s exact search over the current centroids -> (ids, dis)."""
             nonlocal cperm, regrouping, ahead_dmin, gnbr
@@ -323,7 +329,7 @@ class Kmeans:
             if regroup:
                 cperm = be.from_host(regrouping.result())
                 regrouping = None
-            elif it == 2 and init_centroids is None and regrouping is None:
+            elif regrouping is None and ((it == 2 and init_centroids is None) or it == late_regroup):
                 # cold start: regroup once the centroids have settled (taken up when the host is done)
                 regrouping = _grouper().submit(be.group_rows_kd, be.to_host(cent))
             # (bounds of these very centroids and grouping may already be queued: see below)
@@ -391,7 +397,7 @@ class Kmeans:
                       f"objective={st['obj']:g} imbalance={imbalance:.3f} nsplit={nsplit}", flush=True)
         self._last_assign = ids
         if prune:
-            if regrouping is not None and regrouping.done():
+            if regrouping is not None:   # (submitted several iterations ago: done, or about to be)
                 cperm = be.from_host(regrouping.result())
             self._cperm_cache = ((k, d), cperm)
         loss = self._finish(cent)
