@@ -44,6 +44,27 @@ __device__ inline float pairwise_sumsq(const float* a, int n, int stride) {
     return pairwise_sumsq(a, n2, stride) + pairwise_sumsq(a + (size_t)n2 * stride, n - n2, stride);
 }
 
+// The same value for 8 <= n <= 128 computed by 8 adjacent lanes (j = lane & 7 owns numpy's partial sum
+// r[j]; the combining tree is numpy's, and fp32 addition is commutative, so every lane ends with numpy's
+// bits).  All 8 lanes must call it together.
+__device__ inline float pairwise_sumsq_8lanes(const float* a, int n, int j) {
+#pragma clang fp contract(off)
+    float r = a[j] * a[j];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        const float sq = a[i + j] * a[i + j];
+        r = r + sq;
+    }
+    r = r + __shfl_xor(r, 1);
+    r = r + __shfl_xor(r, 2);
+    r = r + __shfl_xor(r, 4);
+    for (; i < n; i++) {
+        const float sq = a[i] * a[i];
+        r = r + sq;
+    }
+    return r;
+}
+
 // ||row|| + 1e-10 as numpy computes it for a float32 row
 __device__ inline float row_denominator(const float* a, int n, int stride) {
     return __builtin_sqrtf(pairwise_sumsq(a, n, stride)) + 1e-10f;

@@ -28,6 +28,7 @@ namespace {
 using namespace logmel;
 
 constexpr int WG = 256;
+constexpr int PREFETCH_REGS = 5;   // x 16 bytes x 256 lanes = 5120 samples per block: 32 frames at hop <= 148, 16 at hop <= 307
 constexpr int TAB_WIN = 0, TAB_TW256 = 512, TAB_TW512 = 1024, TAB_FLOATS = 1536;
 
 struct LogmelParams {
@@ -48,6 +49,9 @@ struct LogmelParams {
     int frame_major, fuse_l2norm;
 };
 
+// PF: the next block's samples are prefetched through registers (needs a block of at most PREFETCH_REGS x WG x 4
+// samples); otherwise they are staged at the top of the block.
+template <bool PF>
 __global__ void __launch_bounds__(WG, 2) logmel_kernel(LogmelParams p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -88,11 +92,57 @@ __global__ void __launch_bounds__(WG, 2) logmel_kernel(LogmelParams p) {
 
     float* mybuf = work + (wave * 4 + grp) * FRAME_LDS_FLOATS;
     const int n_mel_iter = (p.n_mels + 15) >> 4;
-    for (long blk = blockIdx.x; blk < p.n_blocks; blk += gridDim.x) {
+
+    // The samples of a block travel global -> registers -> LDS: the loads of the NEXT block are issued
+    // before this block's frames are computed and land in LDS after them, so their latency is not waited
+    // for.  Blocks in the interior of a clip (no reflection, 16-byte aligned) move 16 bytes per lane.
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int nsamp4 = (nsamp + 3) >> 2;
+    f4 pre[PREFETCH_REGS];
+    auto prefetch = [&](long blk) {
         const long clip = blk / p.blocks_per_clip;
         const int t0 = (int)(blk - clip * p.blocks_per_clip) * p.fpb;
         const float* w = p.wave + clip * p.wave_stride;
-        {
+        const long s0 = (long)t0 * p.hop - NFFT / 2;
+        const bool fast = s0 >= 0 && s0 + 4L * nsamp4 <= p.L && ((reinterpret_cast<uintptr_t>(w + s0) & 15) == 0);
+        if (fast) {
+            const f4* src = reinterpret_cast<const f4*>(w + s0);
+#pragma unroll
+            for (int j = 0; j < PREFETCH_REGS; j++) {
+                const int i4 = tid + WG * j;
+                if (i4 < nsamp4) pre[j] = src[i4];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PREFETCH_REGS; j++) {
+                const int i4 = tid + WG * j;
+                if (i4 < nsamp4) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        long q = s0 + 4 * i4 + e;
+                        if (q < 0) q = -q;                      // reflect, no edge repeat
+                        if (q >= p.L) q = 2 * (p.L - 1) - q;
+                        if (q < 0) q = 0;                       // only reachable for frames past T (never stored)
+                        if (q >= p.L) q = p.L - 1;
+                        pre[j][e] = w[q];
+                    }
+                }
+            }
+        }
+    };
+    if constexpr (PF)
+        if ((long)blockIdx.x < p.n_blocks) prefetch(blockIdx.x);
+    for (long blk = blockIdx.x; blk < p.n_blocks; blk += gridDim.x) {
+        const long clip = blk / p.blocks_per_clip;
+        const int t0 = (int)(blk - clip * p.blocks_per_clip) * p.fpb;
+        if constexpr (PF) {
+#pragma unroll
+            for (int j = 0; j < PREFETCH_REGS; j++) {
+                const int i4 = tid + WG * j;
+                if (i4 < nsamp4) *reinterpret_cast<f4*>(samp + 4 * i4) = pre[j];
+            }
+        } else {
+            const float* w = p.wave + clip * p.wave_stride;
             const long s0 = (long)t0 * p.hop - NFFT / 2;
             for (int i = tid; i < nsamp; i += WG) {
                 long q = s0 + i;
@@ -103,7 +153,9 @@ __global__ void __launch_bounds__(WG, 2) logmel_kernel(LogmelParams p) {
                 samp[i] = w[q];
             }
         }
-        __syncthreads();
+        __syncthreads();  // samples in place; the previous block's staged output has been stored by everybody
+        if constexpr (PF)
+            if (blk + gridDim.x < p.n_blocks) prefetch(blk + gridDim.x);
 
         for (int pass = 0; pass * 16 < p.fpb; pass++) {
             const int f = pass * 16 + wave * 4 + grp;   // frame within the workgroup
@@ -135,16 +187,36 @@ __global__ void __launch_bounds__(WG, 2) logmel_kernel(LogmelParams p) {
         if (p.frame_major) {
             float* den = ostage + p.fpb * opitch;
             if (p.fuse_l2norm) {
-                for (int f = tid; f < nf; f += WG) den[f] = l2n::row_denominator(ostage + f * opitch, p.n_mels, 1);
+                // eight lanes per frame (fpb <= 32 frames: all of them at once); the host fuses only 8 <= n_mels <= 128
+                const int f = tid >> 3;
+                if (f < nf) {
+                    const float ss = l2n::pairwise_sumsq_8lanes(ostage + f * opitch, p.n_mels, tid & 7);
+                    if ((tid & 7) == 0) den[f] = __builtin_sqrtf(ss) + 1e-10f;
+                }
                 __syncthreads();
             }
             float* dst = p.out + ((long)clip * p.T + t0) * p.n_mels;
-            const int total = nf * p.n_mels;
-            for (int e = tid; e < total; e += WG) {
-                const int f = e / p.n_mels, m = e - f * p.n_mels;
-                float v = ostage[f * opitch + m];
-                if (p.fuse_l2norm) v = l2n::divide(v, den[f]);
-                dst[e] = v;
+            if ((p.n_mels & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {   // 16 bytes per lane
+                const int mq = p.n_mels >> 2, total4 = nf * mq;
+                for (int e4 = tid; e4 < total4; e4 += WG) {
+                    const int f = e4 / mq, m = (e4 - f * mq) * 4;
+                    const float* src = ostage + f * opitch + m;
+                    f4 v = {src[0], src[1], src[2], src[3]};
+                    if (p.fuse_l2norm) {
+                        const float dn = den[f];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = l2n::divide(v[e], dn);
+                    }
+                    reinterpret_cast<f4*>(dst)[e4] = v;
+                }
+            } else {
+                const int total = nf * p.n_mels;
+                for (int e = tid; e < total; e += WG) {
+                    const int f = e / p.n_mels, m = e - f * p.n_mels;
+                    float v = ostage[f * opitch + m];
+                    if (p.fuse_l2norm) v = l2n::divide(v, den[f]);
+                    dst[e] = v;
+                }
             }
         } else {
             float* dst = p.out + (long)clip * p.n_mels * p.T + t0;
@@ -154,7 +226,8 @@ __global__ void __launch_bounds__(WG, 2) logmel_kernel(LogmelParams p) {
                 if (f < nf) dst[(long)m * p.T + f] = ostage[f * opitch + m];
             }
         }
-        __syncthreads();  // the staging areas are rewritten by the next block
+        // (no barrier here: the next block's samples go to `samp`, which nobody reads any more, and its
+        // barrier above comes before anybody writes the staged output again)
     }
 }
 
@@ -277,7 +350,10 @@ extern "C" int at_logmel_f32(at_ctx* ctx, const float* wave, int64_t n_clips, in
     AT_REQUIRE(T < (1LL << 31), "at_logmel_f32: too many frames per clip");
     p.wave = wave; p.n_clips = n_clips; p.L = L; p.wave_stride = wave_stride;
     p.hop = hop; p.T = (int)T; p.n_mels = n_mels;
-    p.out = out; p.frame_major = layout == AT_LAYOUT_FRAME_MAJOR; p.fuse_l2norm = fuse_l2norm;
+    // unit rows are fused for 8 <= n_mels <= 128 (numpy's one-level pairwise sum, eight lanes per frame);
+    // other widths get the standalone kernel behind this one, in place
+    const bool fuse_here = fuse_l2norm && n_mels >= 8 && n_mels <= 128;
+    p.out = out; p.frame_major = layout == AT_LAYOUT_FRAME_MAJOR; p.fuse_l2norm = fuse_here;
     // the banded filterbank rides in LDS too unless a dense user filterbank makes it too big
     const size_t fb_ints = (((size_t)3 * n_mels + 3) & ~(size_t)3) + p.fb_nw;
     p.fb_lds = fb_ints * 4 <= 14 * 1024;
@@ -289,9 +365,12 @@ extern "C" int at_logmel_f32(at_ctx* ctx, const float* wave, int64_t n_clips, in
         if (lds <= LDS_TWO_PER_CU || p.fpb == 16) break;
     }
     AT_REQUIRE(lds <= 160 * 1024, "at_logmel_f32: n_mels=%d needs %zu bytes of LDS", n_mels, lds);
+    const bool pf = ((p.fpb - 1) * hop + NFFT + 3) / 4 <= PREFETCH_REGS * WG;   // the block's samples fit the prefetch registers
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
-        AT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&logmel_kernel),
+        AT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&logmel_kernel<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&logmel_kernel<false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
@@ -304,7 +383,9 @@ extern "C" int at_logmel_f32(at_ctx* ctx, const float* wave, int64_t n_clips, in
     if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     long grid = 2L * cus;
     if (grid > p.n_blocks) grid = p.n_blocks;
-    hipLaunchKernelGGL(logmel_kernel, dim3((unsigned)grid), dim3(WG), lds, stream, p);
+    if (pf) hipLaunchKernelGGL(logmel_kernel<true>, dim3((unsigned)grid), dim3(WG), lds, stream, p);
+    else hipLaunchKernelGGL(logmel_kernel<false>, dim3((unsigned)grid), dim3(WG), lds, stream, p);
     AT_LAUNCH_CHECK();
+    if (fuse_l2norm && !fuse_here) return at_l2norm_rows_f32(ctx, out, n_clips * T, n_mels, out, stream_);
     return AT_OK;
 }

@@ -334,6 +334,27 @@ def test_logmel_vs_oracle(be, oracle, n_mels):
     assert np.array_equal(bits(fmn), bits(ref_n))
 
 
+@pytest.mark.parametrize("hop,n_mels", [(64, 64), (100, 40), (256, 64), (400, 20), (512, 6), (128, 136)])
+def test_logmel_other_hops_and_widths(be, oracle, hop, n_mels):
+    """Hops that take the register-prefetch staging with 32 or 16 frames per block and the plain staging
+    (hop > 307), odd clip strides (unaligned rows: the per-sample path), widths whose unit rows are
+    normalised inside the kernel (8..128) and behind it."""
+    rng = np.random.default_rng(hop + n_mels)
+    L = 30001
+    clips = (0.1 * rng.standard_normal((5, L))).astype(np.float32)
+    clips[3, 5000:] = 0.0
+    ref = np.stack([oracle.logmel(c, hop=hop, n_mels=n_mels) for c in clips])
+    got = be.logmel(clips, 22050, 512, hop, n_mels).cpu().numpy()
+    assert got.shape == ref.shape
+    ok = _logmel_tolerance(got, ref)
+    assert ok.all(), f"{(~ok).sum()} of {ok.size} bins outside tolerance"
+    fm = be.logmel(clips, 22050, 512, hop, n_mels, frame_major=True).cpu().numpy()
+    assert np.array_equal(fm.reshape(5, -1, n_mels), got.transpose(0, 2, 1))
+    fmn = be.logmel(clips, 22050, 512, hop, n_mels, frame_major=True, l2norm=True).cpu().numpy()
+    ref_n = fm / (np.linalg.norm(fm, axis=1, keepdims=True) + 1e-10)
+    assert np.array_equal(bits(fmn), bits(ref_n))
+
+
 def test_logmel_full_length_clip_shapes(be, oracle):
     rng = np.random.default_rng(4)
     w = (0.1 * rng.standard_normal((3, 220500))).astype(np.float32)
