@@ -332,6 +332,7 @@ class Kmeans:
             elif regrouping is None and ((it == 2 and init_centroids is None) or it == late_regroup):
                 # cold start: regroup once the centroids have settled (taken up when the host is done)
                 regrouping = _grouper().submit(be.group_rows_kd, be.to_host(cent))
+                regrouping.wanted_at_end = it == late_regroup
             # (bounds of these very centroids and grouping may already be queued: see below)
             dmin = ahead_dmin if (ahead_dmin is not None and not regroup) else be.group_min_dist(cent, cperm)
             ahead_dmin = None
@@ -397,7 +398,8 @@ class Kmeans:
                       f"objective={st['obj']:g} imbalance={imbalance:.3f} nsplit={nsplit}", flush=True)
         self._last_assign = ids
         if prune:
-            if regrouping is not None:   # (submitted several iterations ago: done, or about to be)
+            # (the late one was submitted several iterations ago: done, or about to be)
+            if regrouping is not None and (regrouping.done() or getattr(regrouping, "wanted_at_end", False)):
                 cperm = be.from_host(regrouping.result())
             self._cperm_cache = ((k, d), cperm)
         loss = self._finish(cent)
