@@ -524,8 +524,9 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
         // Two register sets alternate; the list entries are read from LDS two groups before they are
         // needed (as a vector register, turned into a scalar only when used), so neither the LDS round trip
         // nor the fragment loads it addresses sit in front of a group's MFMAs.
-        if constexpr (WPS >= 3) {
-            // experiment: three waves per SIMD hide the fragment loads instead of a second register set
+        if constexpr (WPS >= 3 || D == 128) {
+            // three waves per SIMD hide the fragment loads instead of a second register set (d = 64); at
+            // d = 128 a second set of 8 KiB fragments does not fit the register file beside the rows
             half8 ah[NS];
             f32x4 cn[4];
             for (int i = 0; i < cnt; i++) {
