@@ -812,10 +812,46 @@ __global__ void __launch_bounds__(WG) exact_rows_kernel(const float* __restrict_
     // entry = blockIdx.x; with count_dev the list length is read on the device and the grid strides
     // over it (the launch then needs no host round trip; blocks beyond the list leave at once)
     const unsigned count = count_dev ? *count_dev : gridDim.x;
+    // Entries for which the filter left exactly two candidates need two chains, not a workgroup: one
+    // thread each, before the workgroup-per-row loop (which then passes over them).
+    if (aux) {
+        for (unsigned entry = blockIdx.x * WG + tid; entry < count; entry += gridDim.x * WG) {
+            const uint32_t second = aux[entry];
+            if (second >= (uint32_t)k) continue;
+            const long row = order[list[entry]];
+            const long p = ids[row];
+            if (!(p >= 0 && p < k)) continue;
+            const f32x4* px = reinterpret_cast<const f32x4*>(X + row * D);
+            const f32x4* p1 = reinterpret_cast<const f32x4*>(C + p * D);
+            const f32x4* p2 = reinterpret_cast<const f32x4*>(C + (long)second * D);
+            float xn = 0.0f, cn1 = 0.0f, ip1 = 0.0f, cn2 = 0.0f, ip2 = 0.0f;
+#pragma unroll 4
+            for (int q = 0; q < D / 4; q++) {
+                const f32x4 xq = px[q], c1 = p1[q], c2 = p2[q];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    xn = __builtin_fmaf(xq[e], xq[e], xn);
+                    cn1 = __builtin_fmaf(c1[e], c1[e], cn1);
+                    ip1 = __builtin_fmaf(c1[e], xq[e], ip1);
+                    cn2 = __builtin_fmaf(c2[e], c2[e], cn2);
+                    ip2 = __builtin_fmaf(c2[e], xq[e], ip2);
+                }
+            }
+            const float d1 = __builtin_fmaxf(__builtin_fmaf(-2.0f, ip1, xn + cn1), 0.0f);
+            const float d2 = __builtin_fmaxf(__builtin_fmaf(-2.0f, ip2, xn + cn2), 0.0f);
+            const bool take2 = d2 < d1 || (d2 == d1 && (long)second < p);   // lowest index on a tie
+            ids[row] = take2 ? (long)second : p;
+            if (dist) dist[row] = take2 ? d2 : d1;
+        }
+    }
     for (unsigned entry = blockIdx.x; entry < count; entry += gridDim.x) {
     const long row = order[list[entry]];
+    const uint32_t second = aux ? aux[entry] : NONE;
     const long p = ids[row];
     const bool has = p >= 0 && p < k;
+    // (a two-candidate entry was settled above; its ids[row] may already hold the other candidate, and
+    // its aux word still says so: block-uniform)
+    if (second < (uint32_t)k && has) continue;
     f32x4 xv[D / 4];
     const f32x4* px = reinterpret_cast<const f32x4*>(X + row * D);
 #pragma unroll
@@ -839,16 +875,6 @@ __global__ void __launch_bounds__(WG) exact_rows_kernel(const float* __restrict_
         }
         return __builtin_fmaxf(__builtin_fmaf(-2.0f, ip, xn + cn), 0.0f);
     };
-    const uint32_t second = aux ? aux[entry] : NONE;
-    if (has && second < (uint32_t)k) {  // the filter left exactly two candidates: score both, lowest index on a tie
-        if (tid == 0) {
-            const float d1 = contract_dist(p), d2 = contract_dist((long)second);
-            const bool take2 = d2 < d1 || (d2 == d1 && (long)second < p);
-            ids[row] = take2 ? (long)second : p;
-            if (dist) dist[row] = take2 ? d2 : d1;
-        }
-        continue;
-    }
     float tau = __builtin_inff();
     if (has) {
         const float dh = contract_dist(p);
