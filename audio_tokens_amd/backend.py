@@ -32,6 +32,7 @@ class HostHelpers:
 
     def __init__(self):
         self.lib = _lib.load()
+        self._groupings = {}   # fingerprint of a centroid table -> device grouping (remember_grouping)
 
     def rand_perm(self, n: int, seed: int) -> np.ndarray:
         out = np.empty(n, np.int32)
@@ -67,13 +68,13 @@ class HostHelpers:
         return rows.shape, int(rows.view(np.uint32).sum(dtype=np.uint64))
 
     def remember_grouping(self, rows: np.ndarray, cperm) -> None:
-        cache = self.__dict__.setdefault("_groupings", {})
+        cache = self._groupings
         if len(cache) >= 4:
             cache.pop(next(iter(cache)))
         cache[self._table_fingerprint(rows)] = cperm
 
     def recall_grouping(self, rows: np.ndarray):
-        return self.__dict__.get("_groupings", {}).get(self._table_fingerprint(rows))
+        return self._groupings.get(self._table_fingerprint(rows))
 
     def resample_taps(self, orig_freq: int, new_freq: int):
         """-> (taps float32 [new, 2*width + orig], orig, new, width): torchaudio's sinc_interp_hann kernel."""

@@ -305,6 +305,7 @@ class Kmeans:
         # order and the second sort of the iteration is dropped.
         member_order = prune and xs.shape[0] < 96 * k   # (measured: -8 % per iteration at 32 rows per cluster)
         regrouping = None   # host grouping of newer centroids, under way on the helper thread
+        regrouping_is_late = False
         if prune:
             # The spatial grouping only decides how much the exact sweep can skip.  A warm start begins with
             # the grouping the previous train() ended with while the host regroups the new initial centroids
@@ -324,7 +325,7 @@ class Kmeans:
         late_regroup = self.niter - 6 if self.niter >= 10 else -1
         def pruned_assign(it):
             """Queues iteration `it`'s exact search over the current centroids -> (ids, dis)."""
-            nonlocal cperm, regrouping, ahead_dmin, gnbr
+            nonlocal cperm, regrouping, regrouping_is_late, ahead_dmin, gnbr
             regroup = regrouping is not None and regrouping.done()
             if regroup:
                 cperm = be.from_host(regrouping.result())
@@ -332,7 +333,7 @@ class Kmeans:
             elif regrouping is None and ((it == 2 and init_centroids is None) or it == late_regroup):
                 # cold start: regroup once the centroids have settled (taken up when the host is done)
                 regrouping = _grouper().submit(be.group_rows_kd, be.to_host(cent))
-                regrouping.wanted_at_end = it == late_regroup
+                regrouping_is_late = it == late_regroup
             # (bounds of these very centroids and grouping may already be queued: see below)
             dmin = ahead_dmin if (ahead_dmin is not None and not regroup) else be.group_min_dist(cent, cperm)
             ahead_dmin = None
@@ -399,7 +400,7 @@ class Kmeans:
         self._last_assign = ids
         if prune:
             # (the late one was submitted several iterations ago: done, or about to be)
-            if regrouping is not None and (regrouping.done() or getattr(regrouping, "wanted_at_end", False)):
+            if regrouping is not None and (regrouping.done() or regrouping_is_late):
                 cperm = be.from_host(regrouping.result())
             self._cperm_cache = ((k, d), cperm)
         loss = self._finish(cent)
