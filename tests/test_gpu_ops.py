@@ -78,7 +78,8 @@ def test_assign_hinted_is_hint_independent(be, oracle, n, d, k):
 
 @pytest.mark.parametrize("n,d,k,lds_kernel", [(6000, 64, 300, False), (70000, 64, 8192, False), (3000, 128, 1000, False),
                                               (50000, 128, 4096, False), (20000, 64, 2048, False),
-                                              (33333, 128, 1500, False), (33333, 64, 1500, True), (25001, 64, 16384, False)])
+                                              (33333, 128, 1500, False), (33333, 64, 1500, True), (25001, 64, 16384, False),
+                                              (30001, 128, 16384, False)])   # (last: the shape of BASELINE configs[4])
 def test_assign_pruned_is_exact(be, oracle, monkeypatch, n, d, k, lds_kernel):
     """at_assign_pruned_f32 == brute force, bit for bit, for good guesses (where it prunes), bad
     guesses, missing guesses and exact ties."""
