@@ -523,3 +523,21 @@ def test_group_neighbours_names_the_nearest_means(be, ng, d, nnb):
         others = np.delete(np.arange(ng), g)
         kth = np.sort(d2[g, others])[min(nnb, ng) - 2] if min(nnb, ng) > 1 else 0.0
         assert all(j == g or d2[g, j] <= kth * (1 + 1e-5) for j in chosen)
+
+
+@pytest.mark.parametrize("k,niter", [(2048, 3), (2048, 0), (64, 2)])
+def test_kmeans_rejects_non_finite_input(be, oracle, k, niter):
+    """faiss' isfinite check: the error comes before anything of the call is kept (pruned path at k = 2048,
+    plain path at k = 64, no iteration at all), and the object stays usable."""
+    from audio_tokens_amd.ops import Kmeans
+    rng = np.random.default_rng(k + niter)
+    x = oracle.l2norm_rows(rng.standard_normal((90000, 64)).astype(np.float32))
+    km = Kmeans(64, k, niter=niter, backend=be)
+    for bad_value, where in ((np.nan, 12345), (np.inf, 89999)):
+        xb = x.copy()
+        xb[where, 7] = bad_value
+        with pytest.raises(RuntimeError, match="NaN's or Inf's"):
+            km.train(xb)
+        assert km.iteration_stats == [] and getattr(km, "centroids", None) is None
+    km.train(x)                                                    # and the object is still usable
+    assert km.centroids.shape == (k, 64) and np.isfinite(km.centroids).all()
