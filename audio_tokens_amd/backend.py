@@ -293,6 +293,24 @@ class HipBackend(HostHelpers):
                                                    self._stream()))
         return order, hs
 
+    def visit_order_beside(self, ids, dis, k):
+        """visit_order on a stream of its own (it has its own sort buffers): the caller's stream goes on at
+        once and must call the returned function before it uses the result."""
+        main = torch.cuda.current_stream(self.device)
+        side = getattr(self, "_order_stream", None)
+        if side is None:
+            side = self._order_stream = torch.cuda.Stream(self.device)
+        side.wait_stream(main)                 # ids / dis are complete on the caller's stream
+        with torch.cuda.stream(side):
+            out = self.visit_order(ids, dis, k)
+
+        def join(out=out, ids=ids, dis=dis):   # (ids / dis are kept alive until the sort has been waited for)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            for t in out:
+                t.record_stream(torch.cuda.current_stream(self.device))
+            return out
+        return join
+
     def prune_stats(self, reset=False):
         """(accumulators computed, accumulators of the dense sweep) over this context's exact pruned
         sweeps so far.  Synchronises."""

@@ -359,6 +359,10 @@ class Kmeans:
                 # the short-list accumulation while the long lists are still being summed on the side stream
                 if member_order:
                     part, vorder = be.centroid_accum(xs, ids, k, want_order=True, defer_join=True)
+                elif os.environ.get("AT_ORDER_BESIDE", "1") != "0" and it + 1 < self.niter:
+                    vjoin = be.visit_order_beside(ids, dis, k)   # a third stream: beside both accumulations
+                    part = be.centroid_accum(xs, ids, k, defer_join=True)
+                    vorder = vjoin()
                 else:
                     part = be.centroid_accum(xs, ids, k, defer_join=True)
                     vorder = be.visit_order(ids, dis, k) if it + 1 < self.niter else None
