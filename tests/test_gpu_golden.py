@@ -98,6 +98,29 @@ def test_kmeans_pruned_path_matches_oracle(be, oracle):
     assert 0 < a < t                                         # something was really skipped
 
 
+def test_kmeans_visiting_order_path_matches_oracle(be, oracle):
+    """Enough rows per cluster (>= 96) for the (cluster, distance) visiting order -- its sort runs on a stream of
+    its own beside the accumulations -- cold start and warm start against the oracle."""
+    from audio_tokens_amd.ops import Kmeans
+    rng = np.random.default_rng(19)
+    cen = rng.standard_normal((1024, 64))
+    x = (cen[rng.integers(0, 1024, 230000)] + 0.5 * rng.standard_normal((230000, 64))).astype(np.float32)
+    x = oracle.l2norm_rows(x)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r1 = oracle.kmeans_train(x[:120000], 1024, niter=6)
+        r2 = oracle.kmeans_train(x[120000:], 1024, niter=6, init_centroids=r1.centroids)
+        km = Kmeans(64, 1024, niter=6)
+        km.train(x[:120000])
+        assert np.array_equal(bits(km.centroids), bits(r1.centroids))
+        # (the objective is reported from a fixed fp64 summation tree, the oracle adds in faiss' fp32 order)
+        assert np.allclose(km.obj, r1.obj, rtol=2e-5, atol=0)
+        assert [s["nsplit"] for s in km.iteration_stats] == list(r1.nsplit)
+        km.train(x[120000:], init_centroids=km.centroids)
+        assert np.array_equal(bits(km.centroids), bits(r2.centroids))
+        assert np.allclose(km.obj, r2.obj, rtol=2e-5, atol=0)
+
+
 def test_index_flat_l2_large_search_uses_exact_pruning(be, oracle):
     from audio_tokens_amd.ops import IndexFlatL2
     rng = np.random.default_rng(10)
