@@ -23,6 +23,7 @@ from tqdm import tqdm
 
 from ..audio_tokens_config import AudioTokensConfig
 from ..ops import LogMelSpectrogram, Resample
+from .dataset_splitter import load_split
 
 try:  # optional: only used for decoding when it exists
     import torchaudio as _torchaudio
@@ -75,8 +76,7 @@ class SpectrogramGenerator:
         self.amplitude_to_db_transformer = None
         self.device = self.spec_transformer.backend.device
 
-        with open(config.split_file, "r") as f:
-            self.data_split = json.load(f)
+        self.data_split = load_split(config.split_file)
 
     def run(self):
         for split in ["train", "validation"]:
