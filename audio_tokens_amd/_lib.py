@@ -27,6 +27,7 @@ SIGNATURES = {
     "at_workspace_bytes": (_i64, [_vp]),
     "at_rand_perm_mt19937": (_i32, [_i64, _i64, _vp]),
     "at_rand_perm_prefix_mt19937": (_i32, [_i64, _i64, _i64, _vp]),
+    "at_rand_perm_prefix_device": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "at_mel_filterbank_host": (_i32, [_i32, _i32, _i32, _vp]),
     "at_num_frames": (_i64, [_i64, _i32]),
     "at_split_clusters_host": (_i32, [_i32, _i32, _i64, _vp, _vp, _c.POINTER(_i32)]),
@@ -53,6 +54,8 @@ SIGNATURES = {
     "at_gather_rows_f32": (_i32, [_vp, _vp, _i32, _vp, _i64, _vp, _vp]),
     "at_centroid_accum_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "at_centroid_finalize_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "at_split_clusters_f32": (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "at_lloyd_stats_f64": (_i32, [_vp, _vp, _i32, _vp, _i64, _i32, _vp, _vp]),
     "at_sum_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "at_any_nonfinite_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "at_centroid_accum_defer": (_i32, [_vp, _i32]),

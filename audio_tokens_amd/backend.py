@@ -89,6 +89,14 @@ class HostHelpers:
     def resample_length(self, L: int, orig_freq: int, new_freq: int) -> int:
         return int(self.lib.at_resample_length(L, orig_freq, new_freq))
 
+    @staticmethod
+    def part_layout(k, d):
+        """Packed per-rank partial of one Lloyd iteration, in floats: sums [k*d], counts [k], padding to an even
+        offset, then the rank's objective as one double -> (offset of the double, total length)."""
+        p = k * d + k
+        off = p + (p & 1)
+        return off, off + 2
+
     def split_clusters(self, hassign: np.ndarray, centroids: np.ndarray, n: int) -> int:
         """In place on two C-contiguous float32 host arrays; returns nsplit."""
         assert hassign.dtype == np.float32 and centroids.dtype == np.float32
@@ -453,6 +461,14 @@ class HipBackend(HostHelpers):
                                                     _ptr(approx), ctypes.byref(listed), self._stream()))
         return ids, approx, listed.value
 
+    def rand_perm_prefix_device(self, n: int, seed: int, m: int) -> torch.Tensor:
+        """First m entries of faiss' rand_perm(n, seed) as a device int32 tensor, computed on the device
+        (no host work, no upload); same bits as HostHelpers.rand_perm_prefix."""
+        out = self.empty((m,), torch.int32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_rand_perm_prefix_device(self.ctx.handle, n, seed, m, _ptr(out), self._stream()))
+        return out
+
     def gather_rows(self, x, idx) -> torch.Tensor:
         x = self._f32(x)
         if isinstance(idx, np.ndarray):
@@ -494,7 +510,7 @@ class HipBackend(HostHelpers):
         """parts [n_parts, k*d + k] packed partials (rank order) -> (centroids [k, d], hassign [k])."""
         if parts.dim() == 1:
             parts = parts.unsqueeze(0)
-        assert parts.is_contiguous() and parts.shape[1] == k * d + k
+        assert parts.is_contiguous() and parts.shape[1] >= k * d + k   # (a packed partial may carry the objective behind)
         n_parts = parts.shape[0]
         cent = self.empty((k, d))
         hassign = self.empty((k,))
@@ -505,21 +521,52 @@ class HipBackend(HostHelpers):
                 k, d, _ptr(cent), _ptr(hassign), self._stream()))
         return cent, hassign
 
-    def sum_f64(self, v) -> torch.Tensor:
+    def split_clusters_device(self, hassign, cent, n: int, nsplit_out) -> None:
+        """faiss split_clusters in place on device tensors (hassign [k], cent [k, d]); nsplit_out: int32 [1]."""
+        k, d = cent.shape
+        assert hassign.dtype == torch.float32 and cent.dtype == torch.float32 and nsplit_out.dtype == torch.int32
+        assert hassign.is_contiguous() and cent.is_contiguous() and hassign.numel() == k
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_split_clusters_f32(self.ctx.handle, d, k, n, _ptr(hassign), _ptr(cent), _ptr(nsplit_out),
+                                                      self._stream()))
+
+    def lloyd_stats(self, hassign, parts, k: int, d: int, stats_row) -> None:
+        """stats_row (float64 [2]) <- (objective summed over the packed partials in rank order, imbalance)."""
+        if parts.dim() == 1:
+            parts = parts.unsqueeze(0)
+        off, total = self.part_layout(k, d)
+        assert parts.is_contiguous() and parts.shape[1] == total and stats_row.dtype == torch.float64
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_lloyd_stats_f64(self.ctx.handle, _ptr(hassign), k, _vp(parts.data_ptr() + 4 * off),
+                                                   total // 2, parts.shape[0], _ptr(stats_row), self._stream()))
+
+    def to_host_async(self, t: torch.Tensor):
+        """-> (pinned host tensor, event): the copy is queued on the current stream, the caller's thread goes on;
+        whoever needs the values waits for the event."""
+        h = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+        h.copy_(t, non_blocking=True)
+        return h, self.record_event()
+
+    def sum_f64(self, v, out=None) -> torch.Tensor:
         """Device double scalar (shape [1]); no synchronisation."""
         v = self._f32(v)
-        out = self.empty((1,), torch.float64)
+        if out is None:
+            out = self.empty((1,), torch.float64)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.at_sum_f32(self.ctx.handle, _ptr(v), v.numel(), _ptr(out), self._stream()))
         return out
 
-    def any_nonfinite(self, v) -> bool:
+    def nonfinite_flag(self, v) -> torch.Tensor:
+        """Device int32 [1]: 1 if any value of v is NaN/Inf.  No synchronisation."""
         v = self._f32(v)
         flag = self.empty((1,), torch.int32)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.at_any_nonfinite_f32(self.ctx.handle, _ptr(v), v.numel(), _ptr(flag),
                                                      self._stream()))
-        return bool(flag.item())
+        return flag
+
+    def any_nonfinite(self, v) -> bool:
+        return bool(self.nonfinite_flag(v).item())
 
 
 _default: dict = {}

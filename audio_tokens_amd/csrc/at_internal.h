@@ -33,6 +33,15 @@ enum at_ws_slot {
     WS_CENT_IMG16B,    // fused coarse pass: fp16 image of the group means
     WS_IOTA,           // fused coarse pass: identity permutation of the means
     WS_FILTER_MISC,    // fp16-split filter: max|c|^2 bits, list length; running totals for at_filter_stats
+    WS_PERM_RAW,       // at_rand_perm_prefix_device: draws, (position, step) sort buffers, links
+    WS_PERM_KEYS_A,
+    WS_PERM_KEYS_B,
+    WS_PERM_VALS_A,
+    WS_PERM_VALS_B,
+    WS_PERM_TMP,
+    WS_PERM_PREV,
+    WS_PERM_LAST,
+    WS_SPLIT_LIST,     // at_split_clusters_f32: the clusters that came out empty
     WS_NSLOTS
 };
 

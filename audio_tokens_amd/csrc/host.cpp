@@ -138,16 +138,51 @@ int at_rand_perm_prefix_mt19937(int64_t n, int64_t seed, int64_t m, int32_t* pre
     AT_REQUIRE(n >= 0 && n <= INT32_MAX && m >= 0 && m <= n, "at_rand_perm_prefix_mt19937: bad sizes n=%lld m=%lld",
                (long long)n, (long long)m);
     AT_REQUIRE(prefix != nullptr || m == 0, "at_rand_perm_prefix_mt19937: prefix is null");
-    // Step i of the shuffle swaps position i with a position >= i, so positions < m are final
-    // after step m-1.  The full-length array is still needed as the pool being drawn from.
-    std::vector<int32_t> pool((size_t)n);
-    for (int64_t i = 0; i < n; i++) pool[i] = (int32_t)i;
+    // Step i of the shuffle swaps position i with a position >= i, so positions < m are final after
+    // step m-1 and only the positions those m steps touch ever differ from the identity.  Positions
+    // < m live in `prefix` itself; touched positions >= m in an open-addressing table of <= m entries
+    // (no O(n) pool: at n = 17.2 M, m = 2.1 M that pool was 69 MB of cache misses, 240 ms).  The draws
+    // are sequential by definition but the ADDRESSES they name are known as soon as they are drawn:
+    // a block of draws is generated first and its slots prefetched before the swaps run.
+    const int64_t steps = std::min<int64_t>(m, n - 1);
+    for (int64_t i = 0; i < m; i++) prefix[i] = (int32_t)i;
+    if (steps <= 0) return AT_OK;
+    int bits = 4;
+    while ((int64_t(1) << bits) < 2 * m) bits++;
+    struct Slot { uint32_t key, val; };   // key 0 = empty (keys are positions >= m >= 1)
+    const size_t tsize = size_t(1) << bits;
+    Slot* tab = (Slot*)std::calloc(tsize, sizeof(Slot));
+    if (!tab) return at_fail(AT_E_NOMEM, "at_rand_perm_prefix_mt19937: out of host memory");
+    const uint32_t mask = (uint32_t)(tsize - 1), shift = 32u - (uint32_t)bits;
+    auto home = [&](uint32_t pos) { return (pos * 2654435761u) >> shift; };
     FaissRng rng(seed);
-    for (int64_t i = 0; i < m && i + 1 < n; i++) {
-        int64_t other = i + rng.rand_int((int)(n - i));
-        std::swap(pool[i], pool[other]);
+    constexpr int B = 64;
+    uint32_t other[B];
+    const uint32_t um = (uint32_t)m;
+    for (int64_t i0 = 0; i0 < steps; i0 += B) {
+        const int nb = (int)std::min<int64_t>(B, steps - i0);
+        for (int j = 0; j < nb; j++) {
+            const int64_t i = i0 + j;
+            other[j] = (uint32_t)(i + rng.rand_int((int)(n - i)));
+            if (other[j] < um) __builtin_prefetch(&prefix[other[j]], 1);
+            else __builtin_prefetch(&tab[home(other[j])], 1);
+        }
+        for (int j = 0; j < nb; j++) {
+            const int64_t i = i0 + j;
+            const uint32_t o = other[j];
+            if (o < um) {
+                std::swap(prefix[i], prefix[o]);
+            } else {
+                uint32_t h = home(o);
+                while (tab[h].key != 0 && tab[h].key != o) h = (h + 1) & mask;
+                const uint32_t v = tab[h].key ? tab[h].val : o;
+                tab[h].key = o;
+                tab[h].val = (uint32_t)prefix[i];
+                prefix[i] = (int32_t)v;
+            }
+        }
     }
-    for (int64_t i = 0; i < m; i++) prefix[i] = pool[i];
+    std::free(tab);
     return AT_OK;
 }
 

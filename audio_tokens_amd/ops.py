@@ -18,7 +18,6 @@ rows and the per-cluster partial sums/counts are exchanged once per iteration.
 """
 from __future__ import annotations
 
-import os
 import sys
 import time
 from collections import OrderedDict
@@ -163,24 +162,6 @@ class _Dist:
         return self._all_reduce(v, self.dist.ReduceOp.SUM) if self.on else v
 
 
-_PERM_CACHE: "OrderedDict[tuple, np.ndarray]" = OrderedDict()
-
-
-def _perm_prefix(be, n, seed, m):
-    """First m entries of faiss' rand_perm(n, seed).  A pure function of (n, seed, m): the batches
-    of one run all have the same n, so the few most recent results are kept."""
-    key = (int(n), int(seed), int(m))
-    hit = _PERM_CACHE.get(key)
-    if hit is not None:
-        _PERM_CACHE.move_to_end(key)
-        return hit
-    p = be.rand_perm_prefix(n, seed, m)
-    _PERM_CACHE[key] = p
-    while len(_PERM_CACHE) > 4:
-        _PERM_CACHE.popitem(last=False)
-    return p
-
-
 class Kmeans:
     """faiss.Kmeans(d, k, niter=, verbose=, gpu=) for the reference's use (cluster_creator.py:42-48).
 
@@ -206,16 +187,19 @@ class Kmeans:
         self.min_points_per_centroid = int(min_points_per_centroid)
         self.backend = backend or default_backend()
         self._dist_enabled, self._group = distributed, process_group
-        self.centroids = None          # numpy [k, d] after train(), like faiss
-        self.centroids_device = None   # same, resident
-        self.obj = np.zeros(0, np.float32)
-        self.iteration_stats = []
+        self.centroids_device = None   # [k, d] device tensor after train(); `.centroids` is its numpy copy (lazy)
+        self._centroids_host = None
+        self._iteration_stats, self._stats_pending = [], None
         self.index = None
         self.phase_seconds = None
         self.prune = True  # exact pruning of Lloyd iterations 2..niter (d = 64 / 128 only)
+        self.order_beside = True   # the visiting-order sort on a stream of its own (A/B aid)
 
     # ------------------------------------------------------------------------------------
-    def train(self, x, init_centroids=None):
+    def train(self, x, init_centroids=None, sync=True, check_finite=True):
+        """-> final objective (float), like faiss.  sync=False returns None without waiting for the device:
+        centroids_device is valid in stream order, `.centroids` / `.obj` / `.iteration_stats` wait when read.
+        check_finite=False skips faiss' NaN/Inf scan of x (a host round trip) for callers that have made it."""
         be = self.backend
         k, d = self.k, self.d
         dist = _Dist(self._dist_enabled, self._group)
@@ -230,7 +214,7 @@ class Kmeans:
         if n < k:
             raise RuntimeError(f"Error: 'nx >= k' failed: Number of training points ({n}) should be at "
                                f"least as large as number of clusters ({k})")
-        if dist.any_flag(be.any_nonfinite(x) if n_loc else False, be.device):
+        if check_finite and dist.any_flag(be.any_nonfinite(x) if n_loc else False, be.device):
             raise RuntimeError("Error: 'std::isfinite(x_in[i])' failed: input contains NaN's or Inf's")
 
         # ---- subsample_training_set -------------------------------------------------------
@@ -238,11 +222,11 @@ class Kmeans:
             ns = k * self.max_points_per_centroid
             if self.verbose:
                 print(f"Sampling a subset of {ns} / {n} for training")
-            perm = _perm_prefix(be, n, self.seed, ns)
+            perm = self._subsample_perm(n, ns)      # device int32 [ns]: faiss' rand_perm(n, seed)[:ns]
             if dist.on:
                 mine = (perm >= off) & (perm < off + n_loc)
-                pos = np.flatnonzero(mine).astype(np.int64)      # subsample positions this rank owns
-                xs = be.gather_rows(x, (perm[mine] - off).astype(np.int32))
+                pos = torch.nonzero(mine).reshape(-1)              # subsample positions this rank owns (ascending)
+                xs = be.gather_rows(x, (perm[mine] - off).to(torch.int32).contiguous())
             else:
                 pos = None
                 xs = be.gather_rows(x, perm)
@@ -252,7 +236,7 @@ class Kmeans:
                 print(f"WARNING clustering {ns} points to {k} centroids: please provide at least "
                       f"{k * self.min_points_per_centroid} training points", file=sys.stderr)
             xs = x
-            pos = off + np.arange(n_loc, dtype=np.int64) if dist.on else None
+            pos = off + torch.arange(n_loc, dtype=torch.int64, device=x.device) if dist.on else None
 
         def rows_at(positions):
             """Rows of the (global) subsample at `positions` [m] -> device [m, d], on every rank."""
@@ -260,30 +244,36 @@ class Kmeans:
             if not dist.on:
                 return be.gather_rows(xs, positions.astype(np.int32))
             out = be.zeros((len(positions), d))
-            j = np.searchsorted(pos, positions)
-            ok = (j < len(pos))
-            ok[ok] &= pos[j[ok]] == positions[ok]
-            if ok.any():
-                out[torch.from_numpy(np.flatnonzero(ok)).to(be.device)] = be.gather_rows(xs, j[ok].astype(np.int32))
+            want = be.from_host(positions)
+            if pos.numel():
+                j = torch.searchsorted(pos, want).clamp_(max=pos.numel() - 1)
+                ok = pos[j] == want
+                if bool(ok.any()):
+                    out[ok] = be.gather_rows(xs, j[ok].to(torch.int32).contiguous())
             return dist.sum_bits(out)
 
-        self.iteration_stats = []
+        self._stats_pending = None
+        self._iteration_stats = []
         if ns == k:  # faiss corner case: the training set becomes the centroids
             cent = rows_at(np.arange(k))
-            self.iteration_stats.append(dict(obj=0.0, time=0.0, time_search=0.0, imbalance_factor=1.0, nsplit=0))
-            return self._finish(cent)
+            self._iteration_stats.append(dict(obj=0.0, time=0.0, time_search=0.0, imbalance_factor=1.0, nsplit=0))
+            return self._finish(cent, sync)
 
         if init_centroids is not None:
             cent = be._f32(init_centroids).clone()
             assert tuple(cent.shape) == (k, d), f"init_centroids must be [{k}, {d}]"
         else:
-            cent = rows_at(_perm_prefix(be, ns, self.seed + 1, k))
+            cent = rows_at(be.rand_perm_prefix(ns, self.seed + 1, k))
 
         # ---- Lloyd iterations -------------------------------------------------------------
-        hassign_host = be.host_staging((k,), torch.float32)
-        obj_host = be.host_staging((1,), torch.float64)
+        # Nothing below waits for the device: empty clusters are repaired by a device kernel (same draws, same
+        # bits as faiss' host loop) and {objective, imbalance, nsplit} of every iteration stay in two small device
+        # arrays that are read once, after the last iteration (or per iteration when verbose).
+        niter = self.niter
+        stats_dev = be.zeros((max(niter, 1), 2), torch.float64)
+        nsplit_dev = be.zeros((max(niter, 1),), torch.int32)
+        obj_off, part_len = be.part_layout(k, d)
         t0 = time.time()
-        t_search = 0.0
         prof = self.phase_seconds  # None, or a dict that collects per-phase wall time (debug aid)
 
         def lap(name, t_prev):
@@ -299,13 +289,24 @@ class Kmeans:
         # relies on is computed once per train() -- it only affects how much gets skipped.
         prune = (self.prune and hasattr(be, "assign_pruned") and d in (64, 128) and k >= 1024
                  and (k + 31) // 32 <= 512 and xs.shape[0] >= 4096)
-        ids = dis = order = vorder = ahead_dmin = None
+        ids = dis = order = vorder = None
         # With few rows per cluster on this rank (sharded runs) a cluster fills a tile or two and sorting its
         # rows by distance buys nothing: the member-list order of the accumulation doubles as the visiting
         # order and the second sort of the iteration is dropped.
         member_order = prune and xs.shape[0] < 96 * k   # (measured: -8 % per iteration at 32 rows per cluster)
         regrouping = None   # host grouping of newer centroids, under way on the helper thread
         regrouping_is_late = False
+
+        def regroup_beside(c):
+            """Host grouping of the centroids `c` on the helper thread; the copy to the host is queued on the
+            stream and waited for there, not here."""
+            h, ready = be.to_host_async(c)
+
+            def job():
+                ready.synchronize()
+                return be.group_rows_kd(h.numpy())
+            return _grouper().submit(job)
+
         if prune:
             # The spatial grouping only decides how much the exact sweep can skip.  A warm start begins with
             # the grouping the previous train() ended with while the host regroups the new initial centroids
@@ -316,35 +317,32 @@ class Kmeans:
                 # (continuing from this object's own result: that grouping is of centroids a few iterations
                 # older than these, nothing to redo)
                 if not (init_centroids is getattr(self, "centroids_device", None)
-                        or init_centroids is getattr(self, "centroids", None)):
-                    regrouping = _grouper().submit(be.group_rows_kd, be.to_host(cent))
+                        or init_centroids is self.__dict__.get("_centroids_host")):
+                    regrouping = regroup_beside(cent)
             else:
                 cperm = be.from_host(be.group_rows_kd(be.to_host(cent)))
             gnbr = None
         # a last regrouping near the end: the next warm start and the tokeniser's index begin with it
-        late_regroup = self.niter - 6 if self.niter >= 10 else -1
+        late_regroup = niter - 6 if niter >= 10 else -1
+
         def pruned_assign(it):
             """Queues iteration `it`'s exact search over the current centroids -> (ids, dis)."""
-            nonlocal cperm, regrouping, regrouping_is_late, ahead_dmin, gnbr
-            regroup = regrouping is not None and regrouping.done()
-            if regroup:
+            nonlocal cperm, regrouping, regrouping_is_late, gnbr
+            if regrouping is not None and regrouping.done():
                 cperm = be.from_host(regrouping.result())
                 regrouping = None
             elif regrouping is None and ((it == 2 and init_centroids is None) or it == late_regroup):
                 # cold start: regroup once the centroids have settled (taken up when the host is done)
-                regrouping = _grouper().submit(be.group_rows_kd, be.to_host(cent))
+                regrouping = regroup_beside(cent)
                 regrouping_is_late = it == late_regroup
-            # (bounds of these very centroids and grouping may already be queued: see below)
-            dmin = ahead_dmin if (ahead_dmin is not None and not regroup) else be.group_min_dist(cent, cperm)
-            ahead_dmin = None
+            dmin = be.group_min_dist(cent, cperm)
             if ids is None:   # no previous assignment yet: coarse-to-fine exact search
                 gnbr = be.group_neighbours(be.group_means(cent, cperm), 8)
                 return be.assign_c2f(xs, cent, cperm, dmin, gnbr)
             return be.assign_pruned(xs, cent, vorder if vorder is not None else be.visit_order(ids, dis, k),
                                     cperm, dmin, image_current=True)
 
-        for it in range(self.niter):
-            ts = time.time()
+        for it in range(niter):
             tp = time.perf_counter()
             if prune:
                 ids, dis = pruned_assign(it)
@@ -353,64 +351,84 @@ class Kmeans:
             else:  # same answer, guided by the previous assignment and its member-list order
                 ids, dis = be.assign_hinted(xs, cent, ids, order)
             tp = lap("assign", tp)
-            obj = dist.sum_f64(be.sum_f64(dis))
+            part = be.empty((part_len,))
+            be.sum_f64(dis, out=part[obj_off:obj_off + 2].view(torch.float64))   # this rank's objective rides along
             if prune:
                 # the next iteration's visiting order depends on this assignment only: its sort runs behind
                 # the short-list accumulation while the long lists are still being summed on the side stream
                 if member_order:
-                    part, vorder = be.centroid_accum(xs, ids, k, want_order=True, defer_join=True)
-                elif os.environ.get("AT_ORDER_BESIDE", "1") != "0" and it + 1 < self.niter:
+                    part, vorder = be.centroid_accum(xs, ids, k, out=part, want_order=True, defer_join=True)
+                elif self.order_beside and it + 1 < niter:
                     vjoin = be.visit_order_beside(ids, dis, k)   # a third stream: beside both accumulations
-                    part = be.centroid_accum(xs, ids, k, defer_join=True)
+                    be.centroid_accum(xs, ids, k, out=part, defer_join=True)
                     vorder = vjoin()
                 else:
-                    part = be.centroid_accum(xs, ids, k, defer_join=True)
-                    vorder = be.visit_order(ids, dis, k) if it + 1 < self.niter else None
+                    be.centroid_accum(xs, ids, k, out=part, defer_join=True)
+                    vorder = be.visit_order(ids, dis, k) if it + 1 < niter else None
                 be.centroid_accum_join()
             else:
-                part, order = be.centroid_accum(xs, ids, k, want_order=True)
+                part, order = be.centroid_accum(xs, ids, k, out=part, want_order=True)
             tp = lap("accumulate", tp)
             parts = dist.all_gather_parts(part)
             cent, hassign = be.centroid_finalize(parts, k, d)
-            hassign_host.copy_(hassign, non_blocking=True)
-            obj_host.copy_(obj, non_blocking=True)
-            # the next iteration's centroid-to-group bounds are queued before the host waits for the counts
-            # (they stand unless a cluster came out empty and split_clusters moves centroids): the device
-            # works through the host round trip, which matters once an iteration is a fraction of a ms
-            counts_ready = be.record_event()
-            if prune and it + 1 < self.niter:
-                ahead_dmin = be.group_min_dist(cent, cperm)
-            counts_ready.synchronize()        # (only the read-backs: the bounds kernel keeps running)
-            tp = lap("exchange+finalize+readback", tp)
-            t_search += time.time() - ts  # (the whole iteration is device work here)
-            h = hassign_host.numpy()
-            hd = h.astype(np.float64)
-            imbalance = float((hd * hd).sum() * k / (hd.sum() ** 2))
-            nsplit = 0
-            if (h == 0).any():
-                c_host = be.to_host(cent)
-                h_work = h.copy()
-                nsplit = be.split_clusters(h_work, c_host, ns)
-                cent = be.from_host(c_host)
-                if nsplit:
-                    ahead_dmin = None   # those bounds were of centroids that have just moved
-            tp = lap("split", tp)
-            st = dict(obj=float(np.float32(obj_host.item())), time=time.time() - t0, time_search=t_search,
-                      imbalance_factor=imbalance, nsplit=nsplit)
-            self.iteration_stats.append(st)
+            be.lloyd_stats(hassign, parts, k, d, stats_dev[it])
+            be.split_clusters_device(hassign, cent, ns, nsplit_dev[it:it + 1])
+            tp = lap("exchange+finalize+split", tp)
             if self.verbose:
+                st = self._read_stats(stats_dev[:it + 1], nsplit_dev[:it + 1], t0)[-1]
                 print(f"  Iteration {it} ({st['time']:.2f} s, search {st['time_search']:.2f} s): "
-                      f"objective={st['obj']:g} imbalance={imbalance:.3f} nsplit={nsplit}", flush=True)
+                      f"objective={st['obj']:g} imbalance={st['imbalance_factor']:.3f} nsplit={st['nsplit']}", flush=True)
         self._last_assign = ids
+        self._stats_pending = (stats_dev[:niter], nsplit_dev[:niter], t0)
         if prune:
             # (the late one was submitted several iterations ago: done, or about to be)
             if regrouping is not None and (regrouping.done() or regrouping_is_late):
                 cperm = be.from_host(regrouping.result())
             self._cperm_cache = ((k, d), cperm)
-        loss = self._finish(cent)
-        if prune and hasattr(be, "remember_grouping"):
-            be.remember_grouping(self.centroids, cperm)   # for the index a tokeniser builds from these centroids
-        return loss
+            self._grouping_of_result = cperm
+        return self._finish(cent, sync)
+
+    # -- results ----------------------------------------------------------------------------
+    def _subsample_perm(self, n, m):
+        """faiss' rand_perm(n, seed)[:m] on the device.  A pure function of (n, seed, m); the file batches of one
+        run (one Kmeans object, as in ClusterCreator.run) mostly share n, so the last two are kept."""
+        key = (int(n), self.seed, int(m))
+        cache = self.__dict__.setdefault("_perm_cache", OrderedDict())
+        hit = cache.get(key)
+        if hit is None:
+            hit = cache[key] = self.backend.rand_perm_prefix_device(n, self.seed, m)
+            while len(cache) > 2:
+                cache.popitem(last=False)
+        return hit
+
+    def _read_stats(self, stats_dev, nsplit_dev, t0):
+        be = self.backend
+        st, ns = be.to_host(stats_dev), be.to_host(nsplit_dev)     # (waits for the iterations queued so far)
+        if (ns < 0).any():
+            raise RuntimeError("Kmeans: split_clusters found no donor (every cluster has at most one point)")
+        el = time.time() - t0
+        return [dict(obj=float(np.float32(st[i, 0])), time=el * (i + 1) / len(ns), time_search=el * (i + 1) / len(ns),
+                     imbalance_factor=float(st[i, 1]), nsplit=int(ns[i])) for i in range(len(ns))]
+
+    @property
+    def iteration_stats(self):
+        """faiss' ClusteringIterationStats of the last train() (read back from the device on first use; `time`
+        and `time_search` are the elapsed time spread evenly, the iterations are not timed one by one)."""
+        if self._stats_pending is not None:
+            self._iteration_stats = self._read_stats(*self._stats_pending)
+            self._stats_pending = None
+        return self._iteration_stats
+
+    @property
+    def obj(self):
+        return np.array([s["obj"] for s in self.iteration_stats], dtype=np.float32)
+
+    @property
+    def centroids(self):
+        """numpy [k, d], like faiss (copied from the device on first use)."""
+        if self._centroids_host is None and self.centroids_device is not None:
+            self._centroids_host = self.backend.to_host(self.centroids_device)
+        return self._centroids_host
 
     def lend_grouping(self, table) -> None:
         """Offers the spatial grouping this object ended with to an IndexFlatL2 later filled with `table`
@@ -423,13 +441,21 @@ class Kmeans:
             if table.shape == cached[0]:
                 be.remember_grouping(table, cached[1])
 
-    def _finish(self, cent):
+    def _finish(self, cent, sync=True):
         self.centroids_device = cent
-        self.centroids = self.backend.to_host(cent)
-        self.obj = np.array([s["obj"] for s in self.iteration_stats], dtype=np.float32)
+        self._centroids_host = None
         self.index = IndexFlatL2(self.d, backend=self.backend)
         self.index.add(cent)
-        return float(self.obj[-1]) if self.obj.size else 0.0
+        be = self.backend
+        if getattr(self, "_grouping_of_result", None) is not None and hasattr(be, "remember_grouping"):
+            # for the index a tokeniser later builds from these very centroids (needs their host copy: sync)
+            if sync:
+                be.remember_grouping(self.centroids, self._grouping_of_result)
+            self._grouping_of_result = None
+        if not sync:
+            return None
+        st = self.iteration_stats
+        return float(st[-1]["obj"]) if st else 0.0
 
 
 _GROUPER = None

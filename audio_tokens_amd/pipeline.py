@@ -90,17 +90,20 @@ class DevicePipeline:
                     distributed=self.distributed, process_group=self.process_group, backend=be)
         n_clips = wave_train.shape[0]
         per_rank = max(1, self.clustering_batch_size // self.world)
-        stats = []
+        pending = []
+        bad = be.nonfinite_flag(frames_tr)     # faiss' input check (Clustering::train), once for all batches
         for b, c0 in enumerate(range(0, n_clips, per_rank)):
             c1 = min(n_clips, c0 + per_rank)
             x = frames_tr[c0 * T:c1 * T]
-            if b == 0:
-                km.train(x)
-            else:
-                km.train(x, init_centroids=km.centroids_device)
-            stats.append(km.iteration_stats)
+            # (no host round trip inside: the frames were scanned for NaN/Inf once, above; the statistics of
+            # every batch are read back after the last one)
+            km.train(x, init_centroids=None if b == 0 else km.centroids_device, sync=False, check_finite=False)
+            pending.append(km._stats_pending)
         centroids = be.l2norm_rows(km.centroids_device)
         km.lend_grouping(centroids)
+        if bool(bad.item()):
+            raise RuntimeError("Error: 'std::isfinite(x_in[i])' failed: input contains NaN's or Inf's")
+        stats = [km._read_stats(*p) for p in pending if p is not None]
         sync(); secs["kmeans"] = time.perf_counter() - t0
 
         t0 = time.perf_counter()

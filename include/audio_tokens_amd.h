@@ -194,6 +194,12 @@ int at_filter_probe_f32(at_ctx* ctx, const float* x, int64_t n, int d, const flo
                         const uint32_t* order, const uint32_t* hint_sorted, const int32_t* cperm, int ng,
                         const float* dmin, int64_t* ids, float* approx, int64_t* listed, void* stream);
 
+/* The same m entries as at_rand_perm_prefix_mt19937(n, seed, m, .), bit for bit, computed on the device
+ * (csrc/randperm.hip: the mt19937 stream by one workgroup, then the Fisher-Yates prefix resolved with a
+ * sort of the swap partners instead of 2 M dependent host cache misses).  prefix: DEVICE int32 [m].  Uses
+ * workspace of its own, so it may run on a stream beside other calls on the same context. */
+int at_rand_perm_prefix_device(at_ctx* ctx, int64_t n, int64_t seed, int64_t m, int32_t* prefix, void* stream);
+
 /* out[i] = x[idx[i]] (rows of d floats).  idx: DEVICE int32 [m]. */
 int at_gather_rows_f32(at_ctx* ctx, const float* x, int d, const int32_t* idx, int64_t m,
                        float* out, void* stream);
@@ -222,6 +228,19 @@ int at_centroid_accum_join(at_ctx* ctx, void* stream);
 int at_centroid_finalize_f32(at_ctx* ctx, const float* sums_parts, int64_t sums_part_stride,
                              const float* counts_parts, int64_t counts_part_stride, int n_parts,
                              int k, int d, float* centroids, float* hassign, void* stream);
+
+/* at_split_clusters_host on DEVICE buffers (hassign [k], centroids [k][d], both updated in place), same bits:
+ * one workgroup regenerates the mt19937(1234) stream in LDS and runs the cyclic acceptance scans, so a Lloyd
+ * iteration needs no host round trip to learn whether a cluster came out empty.  *nsplit_out (DEVICE int32)
+ * receives the number of re-seeded clusters (-1: no donor exists, i.e. every cluster has at most one member). */
+int at_split_clusters_f32(at_ctx* ctx, int d, int k, int64_t n, float* hassign, float* centroids,
+                          int32_t* nsplit_out, void* stream);
+
+/* Statistics of one Lloyd iteration, left on the device (faiss ClusteringIterationStats): stats[0] = objective =
+ * the doubles obj_parts[p * obj_part_stride], p < n_parts, added in ascending p (one per data-parallel rank: its
+ * at_sum_f32 of the distances); stats[1] = imbalance factor k * sum(h^2) / (sum h)^2 of hassign [k]. */
+int at_lloyd_stats_f64(at_ctx* ctx, const float* hassign, int k, const double* obj_parts,
+                       int64_t obj_part_stride, int n_parts, double* stats, void* stream);
 
 /* *out (DEVICE double) = sum of v[0..n) accumulated in double with a fixed reduction tree. */
 int at_sum_f32(at_ctx* ctx, const float* v, int64_t n, double* out, void* stream);

@@ -75,22 +75,52 @@ class OracleBackend(HostHelpers):
         np.add.at(sums, ids.numpy(), x)          # unbuffered, ascending i: the sequential fp32 sum
         np.add.at(counts, ids.numpy(), np.float32(1))
         part = torch.from_numpy(np.concatenate([sums.ravel(), counts]))
+        if out is not None:
+            out[: k * d + k] = part
+            part = out
         return (part, None) if want_order else part
 
+    def rand_perm_prefix_device(self, n, seed, m):
+        return torch.from_numpy(self.rand_perm_prefix(n, seed, m))
+
+    def split_clusters_device(self, hassign, cent, n, nsplit_out):
+        h, c = hassign.numpy(), cent.numpy()       # (views: updated in place, as the device kernel does)
+        nsplit_out[0] = self.split_clusters(h, c, n) if (h == 0).any() else 0
+
+    def lloyd_stats(self, hassign, parts, k, d, stats_row):
+        off, total = self.part_layout(k, d)
+        parts = parts.reshape(-1, total)
+        obj = 0.0
+        for p in parts:                          # ascending rank order
+            obj += float(p[off:off + 2].view(torch.float64)[0])
+        h = hassign.double().numpy()
+        stats_row[0] = obj
+        stats_row[1] = float((h * h).sum() * k / (h.sum() ** 2))
+
+    def to_host_async(self, t):
+        class _Done:
+            def synchronize(self):
+                pass
+        return t.clone(), _Done()
+
     def centroid_finalize(self, parts, k, d):
-        parts = parts.reshape(-1, k * d + k).numpy()
+        parts = parts.reshape(-1, self.part_layout(k, d)[1]).numpy()
         tot = np.zeros(k * d, np.float32)
         cnt = np.zeros(k, np.float32)
         for p in parts:                          # ascending rank order
             tot = tot + p[: k * d]
-            cnt = cnt + p[k * d:]
+            cnt = cnt + p[k * d: k * d + k]
         cent = tot.reshape(k, d).copy()
         nz = cnt != 0
         cent[nz] = cent[nz] * (np.float32(1.0) / cnt[nz])[:, None]
         return torch.from_numpy(cent), torch.from_numpy(cnt)
 
-    def sum_f64(self, v):
-        return torch.tensor([float(self._f32(v).double().sum())], dtype=torch.float64)
+    def sum_f64(self, v, out=None):
+        r = torch.tensor([float(self._f32(v).double().sum())], dtype=torch.float64)
+        if out is not None:
+            out.copy_(r)
+            return out
+        return r
 
     def any_nonfinite(self, v):
         return not bool(torch.isfinite(self._f32(v)).all())
