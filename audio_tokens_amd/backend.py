@@ -186,11 +186,18 @@ class HipBackend(HostHelpers):
             out = self.empty(shape)
         else:
             assert out.is_contiguous() and out.dtype == torch.float32 and out.numel() == n_clips * T * n_mels
+        rec = self.assign_trace
+        if rec is not None:  # bench.py: HIP events on the launch stream around the launch
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.device))
         with torch.cuda.device(self.device):
             _lib.check(self.lib.at_logmel_f32(
                 self.ctx.handle, _ptr(wave), n_clips, L, wave.stride(0), sample_rate, n_fft, hop, n_mels,
                 _ptr(fbt), _ptr(out), _lib.AT_LAYOUT_FRAME_MAJOR if frame_major else _lib.AT_LAYOUT_MEL_MAJOR,
                 1 if l2norm else 0, self._stream()))
+        if rec is not None:
+            e1.record(torch.cuda.current_stream(self.device))
+            rec.append(("logmel", n_clips * T, n_mels, hop, e0, e1))
         return out
 
     def resample(self, wave, orig_freq: int, new_freq: int) -> torch.Tensor:
@@ -500,10 +507,17 @@ class HipBackend(HostHelpers):
         sorted_ids = self.empty((n,), torch.int32) if want_order else None
         with torch.cuda.device(self.device):
             _lib.check(self.lib.at_centroid_accum_defer(self.ctx.handle, 1 if defer_join else 0))
-            _lib.check(self.lib.at_centroid_accum_f32(
-                self.ctx.handle, _ptr(x), n, d, _ptr(ids), k, _ptr(out), _vp(out.data_ptr() + 4 * k * d),
-                _ptr(order), _ptr(sorted_ids), self._stream()))
-            _lib.check(self.lib.at_centroid_accum_defer(self.ctx.handle, 0))
+            try:
+                _lib.check(self.lib.at_centroid_accum_f32(
+                    self.ctx.handle, _ptr(x), n, d, _ptr(ids), k, _ptr(out), _vp(out.data_ptr() + 4 * k * d),
+                    _ptr(order), _ptr(sorted_ids), self._stream()))
+            except Exception:
+                # a failed call must not leave a half-deferred join behind: wait for whatever the side stream
+                # was given and go back to the joined form
+                self.lib.at_centroid_accum_join(self.ctx.handle, self._stream())
+                raise
+            finally:
+                self.lib.at_centroid_accum_defer(self.ctx.handle, 0)
         return (out, (order, sorted_ids)) if want_order else out
 
     def centroid_finalize(self, parts, k, d):

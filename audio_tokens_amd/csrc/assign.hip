@@ -1282,7 +1282,24 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
         // Stage 1: fp16-split filter (filter.hip) names the winner of every row whose runner-up is
         // provably out of reach and lists the others; stage 2 below redoes the listed rows with the
         // fp32 sweep.  Coarse mode (guesses only) needs neither the list nor stage 2.
-        int rcp = at_filter_resolve_pending(ctx);   // statistics (and the list-length verdict) of the previous call
+        // statistics (and the list-length verdicts) of earlier calls whose words have arrived: polled, not waited for
+        int rcp = at_filter_resolve_pending(ctx, false);
+        if (rcp) return rcp;
+        const char* sy = std::getenv("AT_FILTER_SYNC");  // A/B aid: 1 = always the synchronous form
+        const bool async_form = mode == 0 && !ctx->filter_force_sync && !(sy && std::atoi(sy) == 1);
+        int slot = AT_FILTER_RING;
+        if (async_form) {
+            if (ctx->fring_count == AT_FILTER_RING) {   // the host is a whole ring ahead of the device: wait for the oldest
+                AT_HIP(hipEventSynchronize(ctx->fring[ctx->fring_head].copied));
+                rcp = at_filter_resolve_pending(ctx, false);
+                if (rcp) return rcp;
+            }
+            slot = (ctx->fring_head + ctx->fring_count) % AT_FILTER_RING;
+        } else if (mode == 0) {
+            rcp = at_filter_resolve_pending(ctx, true);   // the synchronous form reads its words at once: keep the order
+            if (rcp) return rcp;
+        }
+        rcp = at_filter_use_slot_events(ctx, slot);
         if (rcp) return rcp;
         unsigned* misc = static_cast<unsigned*>(at_ws(ctx, WS_FILTER_MISC, 256, stream));
         uint32_t* list = static_cast<uint32_t*>(at_ws(ctx, WS_FILTER_LIST, sizeof(uint32_t) * 5 * ((size_t)n + 64), stream));
@@ -1306,21 +1323,17 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
         // n/16 rows (badly scaled data) was still answered correctly (the redo strides over any length),
         // but switches this context to the synchronous form below, whose redo of long lists is the
         // fp32 MFMA sweep.
-        const char* sy = std::getenv("AT_FILTER_SYNC");  // A/B aid: 1 = always the synchronous form
-        if (!ctx->filter_force_sync && !(sy && std::atoi(sy) == 1)) {
-            if (!ctx->filter_host_misc) {
-                AT_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->filter_host_misc), 64 * sizeof(unsigned), hipHostMallocDefault));
-                AT_HIP(hipEventCreateWithFlags(&ctx->filter_copied, hipEventDisableTiming));
-            }
+        if (async_form) {
+            at_filter_slot& fs = ctx->fring[slot];
             int64_t wgs = n / 64;                      // enough workgroups for a list of 1.5 % of the rows in one go
             if (wgs < 256) wgs = 256;
             if (wgs > 65535) wgs = 65535;
             rc = at_filter_redo_rows(ctx, x, D, c, k, list, wgs, order, cperm, dmin, ng, misc, aux, ids, dist, misc + 1, stream);
             if (rc) return rc;
-            AT_HIP(hipMemcpyAsync(ctx->filter_host_misc, misc, 64 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-            AT_HIP(hipEventRecord(ctx->filter_copied, stream));
-            ctx->filter_pending = 1;
-            ctx->filter_pending_rows = n;
+            AT_HIP(hipMemcpyAsync(fs.host_misc, misc, 64 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+            AT_HIP(hipEventRecord(fs.copied, stream));
+            fs.rows = n;
+            ctx->fring_count++;
             return AT_OK;
         }
         unsigned host_misc[64];
@@ -1418,24 +1431,49 @@ extern "C" int at_prune_mask_f32(at_ctx* ctx, const float* x, int64_t n, int d, 
 
 // fp16-split filter: rows swept / rows handed to the fp32 redo since the last reset.
 // Folds the statistics words an asynchronous exact call left in pinned memory into the totals.
-int at_filter_resolve_pending(at_ctx* ctx) {
-    if (!ctx->filter_pending) return AT_OK;
-    AT_HIP(hipEventSynchronize(ctx->filter_copied));
-    const unsigned* hm = ctx->filter_host_misc;
-    const unsigned listed = hm[1];
-    ctx->filter_rows += ctx->filter_pending_rows;
-    ctx->filter_listed += listed;
-    for (int i = 0; i < 16; i++) {
-        ctx->filter_tiles += hm[4 + 2 * i];
-        ctx->filter_refined += hm[5 + 2 * i];
+int at_filter_use_slot_events(at_ctx* ctx, int slot) {
+    if (!ctx->filter_host_misc) {
+        AT_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->filter_host_misc), (size_t)(AT_FILTER_RING + 1) * 64 * sizeof(unsigned),
+                             hipHostMallocDefault));
+        for (int s = 0; s <= AT_FILTER_RING; s++) ctx->fring[s].host_misc = ctx->filter_host_misc + (size_t)s * 64;
     }
-    float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, ctx->filter_ev[0], ctx->filter_ev[1]) == hipSuccess) {
-        ctx->filter_ms += ms;
-        ctx->filter_launches++;
+    at_filter_slot& fs = ctx->fring[slot];
+    if (!fs.copied) AT_HIP(hipEventCreateWithFlags(&fs.copied, hipEventDisableTiming));
+    for (int i = 0; i < 2; i++)
+        if (!fs.ev[i])  // no system-scope release at the event: it would charge an L2 write-back to the kernel
+            AT_HIP(hipEventCreateWithFlags(&fs.ev[i], hipEventDisableSystemFence));
+    ctx->filter_ev[0] = fs.ev[0];
+    ctx->filter_ev[1] = fs.ev[1];
+    return AT_OK;
+}
+
+int at_filter_resolve_pending(at_ctx* ctx, bool wait_all) {
+    while (ctx->fring_count > 0) {
+        at_filter_slot& fs = ctx->fring[ctx->fring_head];
+        if (wait_all) {
+            AT_HIP(hipEventSynchronize(fs.copied));
+        } else {
+            const hipError_t q = hipEventQuery(fs.copied);
+            if (q == hipErrorNotReady) break;
+            AT_HIP(q);
+        }
+        const unsigned* hm = fs.host_misc;
+        const unsigned listed = hm[1];
+        ctx->filter_rows += fs.rows;
+        ctx->filter_listed += listed;
+        for (int i = 0; i < 16; i++) {
+            ctx->filter_tiles += hm[4 + 2 * i];
+            ctx->filter_refined += hm[5 + 2 * i];
+        }
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, fs.ev[0], fs.ev[1]) == hipSuccess) {
+            ctx->filter_ms += ms;
+            ctx->filter_launches++;
+        }
+        if ((int64_t)listed * 16 > fs.rows) ctx->filter_force_sync = 1;
+        ctx->fring_head = (ctx->fring_head + 1) % AT_FILTER_RING;
+        ctx->fring_count--;
     }
-    if ((int64_t)listed * 16 > ctx->filter_pending_rows) ctx->filter_force_sync = 1;
-    ctx->filter_pending = 0;
     return AT_OK;
 }
 
@@ -1443,7 +1481,7 @@ extern "C" int at_filter_stats(at_ctx* ctx, int64_t* rows, int64_t* listed, doub
                                int64_t* tiles, int64_t* refined, int reset) {
     AT_REQUIRE(ctx && rows && listed, "at_filter_stats: bad arguments");
     {
-        int rcp = at_filter_resolve_pending(ctx);
+        int rcp = at_filter_resolve_pending(ctx, true);
         if (rcp) return rcp;
     }
     *rows = ctx->filter_rows;

@@ -45,6 +45,17 @@ enum at_ws_slot {
     WS_NSLOTS
 };
 
+// Asynchronous exact calls leave their statistics words (and the events that time their stage-1 kernel) in a
+// ring of slots; slots are folded into the totals when their copy has arrived -- polled, never waited for, unless
+// the ring is full or a query asks for the totals.
+constexpr int AT_FILTER_RING = 64;
+struct at_filter_slot {
+    unsigned* host_misc;   // pinned, 64 words
+    hipEvent_t copied;     // behind the D2H copy of the words
+    hipEvent_t ev[2];      // around the stage-1 kernel
+    int64_t rows;
+};
+
 struct at_ctx {
     int device;
     void* ws[WS_NSLOTS];
@@ -52,6 +63,8 @@ struct at_ctx {
     // cached description of what WS_LOGMEL_FB currently holds
     int fb_sr, fb_nfft, fb_nmels, fb_nw, fb_hop, fb_quads;
     const float* fb_user;
+    float* fb_user_copy;   // host copy of the user filterbank the tables were built from (malloc'd; compared per call)
+    int n_cus;             // multiProcessorCount of the device (read once in at_create)
     int rs_orig, rs_new;  // what WS_RESAMPLE_TAPS currently holds
     int64_t filter_rows, filter_listed;  // fp16-split filter: rows swept / rows handed to the fp32 redo
     hipEvent_t filter_ev[2];             // around the stage-1 kernel of exact calls (created on first use)
@@ -61,10 +74,10 @@ struct at_ctx {
     // asynchronous exact calls: the statistics words of the last call are copied to pinned memory and folded
     // into the totals at the next call / query; a call whose list was long switches the context to the
     // synchronous form (with its fp32 MFMA redo) from then on
-    unsigned* filter_host_misc;          // pinned, 64 words
-    hipEvent_t filter_copied;
-    int filter_pending, filter_force_sync;
-    int64_t filter_pending_rows;
+    unsigned* filter_host_misc;          // pinned, (AT_FILTER_RING + 1) x 64 words
+    at_filter_slot fring[AT_FILTER_RING + 1];   // (the extra slot lends its timing events to the synchronous form)
+    int fring_head, fring_count;         // oldest pending slot, number of pending slots
+    int filter_force_sync;
   // 32x32 tiles multiplied (hi*hi) / refined (lo products too), exact calls
     hipStream_t side_stream;             // centroid_accum: long member lists beside the short ones
     hipEvent_t side_ev[2];
@@ -127,6 +140,9 @@ int at_group_min_dist_f16(at_ctx* ctx, const float* c, int k, int d, const int32
 int at_filter_coarse(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k, const int32_t* cperm, int ng,
                      const float* means, const uint32_t* gnbr, int64_t* ids, float* dist, hipStream_t stream);
 
-int at_filter_resolve_pending(at_ctx* ctx);
+// wait_all: fold every pending slot (blocking); otherwise only those whose copy has already arrived
+int at_filter_resolve_pending(at_ctx* ctx, bool wait_all);
+// makes ctx->filter_ev name the timing events of ring slot `slot` (created on first use)
+int at_filter_use_slot_events(at_ctx* ctx, int slot);
 
 static inline bool at_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -1086,9 +1086,10 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
     const dim3 grid((unsigned)((n + 32 * NB - 1) / (32 * NB)));
     AT_REQUIRE(d == 64 || d == 128, "at_filter_sweep: d must be 64 or 128");
     if (collect) {  // exact calls synchronise anyway: time the kernel for at_filter_stats
-        for (int i = 0; i < 2; i++)
-            if (!ctx->filter_ev[i])  // no system-scope release at the event: it would charge an L2 write-back to the kernel
-                AT_HIP(hipEventCreateWithFlags(&ctx->filter_ev[i], hipEventDisableSystemFence));
+        if (!ctx->filter_ev[0]) {   // (a caller that did not pick a ring slot: the spare pair)
+            int rce = at_filter_use_slot_events(ctx, AT_FILTER_RING);
+            if (rce) return rce;
+        }
         AT_HIP(hipEventRecord(ctx->filter_ev[0], stream));
     }
 #define AT_FILTER_LAUNCH(DD, NBB, GG, FF, GRID)                                                                      \

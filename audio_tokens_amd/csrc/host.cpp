@@ -49,6 +49,7 @@ int at_create(int device, at_ctx** out) {
     if (!c) return at_fail(AT_E_NOMEM, "at_create: out of host memory");
     std::memset(c, 0, sizeof *c);
     c->device = device;
+    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     *out = c;
     return AT_OK;
 }
@@ -61,13 +62,17 @@ void at_destroy(at_ctx* ctx) {
     (void)hipDeviceSynchronize();
     for (int i = 0; i < WS_NSLOTS; i++)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
-    for (int i = 0; i < 2; i++) {
-        if (ctx->filter_ev[i]) (void)hipEventDestroy(ctx->filter_ev[i]);
+    for (int i = 0; i < 2; i++)
         if (ctx->side_ev[i]) (void)hipEventDestroy(ctx->side_ev[i]);
+    for (int s = 0; s <= AT_FILTER_RING; s++) {   // (ctx->filter_ev only aliases a slot's pair)
+        at_filter_slot& fs = ctx->fring[s];
+        if (fs.copied) (void)hipEventDestroy(fs.copied);
+        for (int i = 0; i < 2; i++)
+            if (fs.ev[i]) (void)hipEventDestroy(fs.ev[i]);
     }
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
-    if (ctx->filter_copied) (void)hipEventDestroy(ctx->filter_copied);
     if (ctx->filter_host_misc) (void)hipHostFree(ctx->filter_host_misc);
+    std::free(ctx->fb_user_copy);
     (void)hipSetDevice(prev);
     delete ctx;
 }
@@ -84,9 +89,11 @@ int64_t at_workspace_bytes(const at_ctx* ctx) {
 void* at_ws(at_ctx* ctx, int slot, size_t bytes, hipStream_t stream) {
     if (bytes == 0) bytes = 16;
     if (ctx->ws_bytes[slot] >= bytes) return ctx->ws[slot];
-    // Work already queued on `stream` may still read the old buffer: drain before freeing.
+    // Work already queued may still read the old buffer -- on `stream`, or on the context's side stream / a
+    // caller's second stream (the slots are per purpose, not per stream): drain the device before freeing.
     if (ctx->ws[slot]) {
-        if (hipStreamSynchronize(stream) != hipSuccess) return nullptr;
+        (void)stream;
+        if (hipDeviceSynchronize() != hipSuccess) return nullptr;
         (void)hipFree(ctx->ws[slot]);
         ctx->ws[slot] = nullptr;
         ctx->ws_bytes[slot] = 0;

@@ -16,6 +16,7 @@
 // filterbank as a banded dot product per filter (only the non-zero taps), 10*log10, and a staged
 // coalesced store.  Algorithmic HBM traffic: hop*4 bytes in + n_mels*4 bytes out per frame.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -243,18 +244,24 @@ constexpr size_t LDS_TWO_PER_CU = 80 * 1024;  // two workgroups of this size sha
 int build_tables(at_ctx* ctx, int sample_rate, int n_mels, int hop, const float* fb_user_dev, hipStream_t stream,
                  const float** tabs, const int** st, const int** ln, const int** of, const float** wt,
                  int* n_weights, int* quads) {
-    const bool cached = ctx->ws[WS_LOGMEL_FB] && ctx->fb_sr == sample_rate && ctx->fb_nfft == NFFT &&
-                        ctx->fb_nmels == n_mels && ctx->fb_user == fb_user_dev && ctx->fb_hop == hop;
+    bool cached = ctx->ws[WS_LOGMEL_FB] && ctx->fb_sr == sample_rate && ctx->fb_nfft == NFFT &&
+                  ctx->fb_nmels == n_mels && (ctx->fb_user != nullptr) == (fb_user_dev != nullptr) && ctx->fb_hop == hop;
     std::vector<float> fb((size_t)NBIN * n_mels);
+    if (fb_user_dev) {
+        // A caller's filterbank is never trusted by address (allocators hand the same address to the next
+        // tensor of the same shape, and a tensor can be rewritten in place): its VALUES are read back and
+        // compared with the copy the resident tables were built from.  66 KB and one stream synchronisation
+        // per call -- the price of the option; the library's own filterbank (fb_or_null == NULL) pays nothing.
+        AT_HIP(hipStreamSynchronize(stream));
+        AT_HIP(hipMemcpy(fb.data(), fb_user_dev, fb.size() * sizeof(float), hipMemcpyDeviceToHost));
+        cached = cached && ctx->fb_user_copy && std::memcmp(ctx->fb_user_copy, fb.data(), fb.size() * sizeof(float)) == 0;
+    }
     std::vector<int> start(n_mels), len(n_mels), off(n_mels);
     std::vector<float> wts;
     size_t bytes = 0;
     char* base = nullptr;
     if (!cached) {
-        if (fb_user_dev) {
-            AT_HIP(hipStreamSynchronize(stream));
-            AT_HIP(hipMemcpy(fb.data(), fb_user_dev, fb.size() * sizeof(float), hipMemcpyDeviceToHost));
-        } else {
+        if (!fb_user_dev) {
             int rc = at_mel_filterbank_host(sample_rate, NFFT, n_mels, fb.data());
             if (rc) return rc;
         }
@@ -305,8 +312,16 @@ int build_tables(at_ctx* ctx, int sample_rate, int n_mels, int hop, const float*
         q = blob.data() + sizeof(float) * TAB_FLOATS + sizeof(int) * nint;
         if (!wts.empty()) std::memcpy(q, wts.data(), sizeof(float) * wts.size());
         bytes = blob.size();
-        AT_HIP(hipStreamSynchronize(stream));
+        // a launch on ANY stream may still be reading the tables about to be replaced
+        AT_HIP(hipDeviceSynchronize());
         AT_HIP(hipMemcpy(base, blob.data(), bytes, hipMemcpyHostToDevice));
+        std::free(ctx->fb_user_copy);
+        ctx->fb_user_copy = nullptr;
+        if (fb_user_dev) {
+            ctx->fb_user_copy = static_cast<float*>(std::malloc(fb.size() * sizeof(float)));
+            if (!ctx->fb_user_copy) return at_fail(AT_E_NOMEM, "at_logmel_f32: out of host memory");
+            std::memcpy(ctx->fb_user_copy, fb.data(), fb.size() * sizeof(float));
+        }
         ctx->fb_sr = sample_rate; ctx->fb_nfft = NFFT; ctx->fb_nmels = n_mels; ctx->fb_user = fb_user_dev;
         ctx->fb_nw = (int)wts.size();
         ctx->fb_hop = hop;
@@ -378,10 +393,7 @@ extern "C" int at_logmel_f32(at_ctx* ctx, const float* wave, int64_t n_clips, in
     p.n_blocks = (long)p.blocks_per_clip * n_clips;
     // persistent workgroups: two per CU (what the LDS footprint allows), each walking a strided share
     // of the blocks with its window / twiddle tables in registers
-    int cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    long grid = 2L * cus;
+    long grid = 2L * ctx->n_cus;
     if (grid > p.n_blocks) grid = p.n_blocks;
     if (pf) hipLaunchKernelGGL(logmel_kernel<true>, dim3((unsigned)grid), dim3(WG), lds, stream, p);
     else hipLaunchKernelGGL(logmel_kernel<false>, dim3((unsigned)grid), dim3(WG), lds, stream, p);

@@ -44,7 +44,7 @@ class PipelineResult:
 class DevicePipeline:
     def __init__(self, n_mels=64, vocab_size=500, niter=20, sample_rate=22050, n_fft=512, hop_length=128,
                  clustering_batch_size=10000, spectrogram_batch_size=5000, distributed=False,
-                 process_group=None, backend=None, verbose=False):
+                 process_group=None, backend=None, verbose=False, prune=True):
         self.n_mels, self.vocab_size, self.niter = n_mels, vocab_size, niter
         self.sample_rate, self.n_fft, self.hop_length = sample_rate, n_fft, hop_length
         self.clustering_batch_size = clustering_batch_size
@@ -52,6 +52,7 @@ class DevicePipeline:
         self.distributed, self.process_group = distributed, process_group
         self.be = backend or default_backend()
         self.verbose = verbose
+        self.prune = prune   # False: plain dense sweeps everywhere (bench.py's floor / verification run)
         self.world = 1
         if distributed:
             import torch.distributed as dist
@@ -88,6 +89,7 @@ class DevicePipeline:
         t0 = time.perf_counter()
         km = Kmeans(self.n_mels, self.vocab_size, niter=self.niter, verbose=self.verbose,
                     distributed=self.distributed, process_group=self.process_group, backend=be)
+        km.prune = self.prune
         n_clips = wave_train.shape[0]
         per_rank = max(1, self.clustering_batch_size // self.world)
         pending = []
@@ -101,13 +103,11 @@ class DevicePipeline:
             pending.append(km._stats_pending)
         centroids = be.l2norm_rows(km.centroids_device)
         km.lend_grouping(centroids)
-        if bool(bad.item()):
-            raise RuntimeError("Error: 'std::isfinite(x_in[i])' failed: input contains NaN's or Inf's")
-        stats = [km._read_stats(*p) for p in pending if p is not None]
         sync(); secs["kmeans"] = time.perf_counter() - t0
 
         t0 = time.perf_counter()
         index = IndexFlatL2(self.n_mels, backend=be)          # SpecTokenizer.load_centroid_index
+        index.prune = self.prune
         index.add(centroids)
         tok_tr, _ = index.assign(frames_tr, want_dist=False)  # index.search(x, 1), ids only
         tok_va = be.empty((0,), torch.int64)
@@ -115,6 +115,10 @@ class DevicePipeline:
             tok_va, _ = index.assign(frames_va, want_dist=False)
         sync(); secs["tokenize"] = time.perf_counter() - t0
 
+        # the only host round trips of the pass, behind everything that was queued
+        if bool(bad.item()):
+            raise RuntimeError("Error: 'std::isfinite(x_in[i])' failed: input contains NaN's or Inf's")
+        stats = [km._read_stats(*p) for p in pending if p is not None]
         return PipelineResult(centroids, tok_tr, tok_va, T, secs, stats)
 
     # -- host-resident inputs ------------------------------------------------------------------
@@ -179,6 +183,7 @@ class DevicePipeline:
         t0 = time.perf_counter()
         km = Kmeans(self.n_mels, self.vocab_size, niter=self.niter, verbose=self.verbose,
                     distributed=self.distributed, process_group=self.process_group, backend=be)
+        km.prune = self.prune
         per_rank = max(1, self.clustering_batch_size // self.world)
         frames = be.empty((min(per_rank, n_clips) * T, self.n_mels))     # one k-means batch at a time
         stats = []
@@ -196,6 +201,7 @@ class DevicePipeline:
 
         t0 = time.perf_counter()
         index = IndexFlatL2(self.n_mels, backend=be)
+        index.prune = self.prune
         index.add(centroids)
 
         def tokenise(wave_host, feeder):

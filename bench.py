@@ -6,13 +6,22 @@
          --master-port P bench.py --gpus N --steps K --warmup W
 
 Metric (BASELINE.json): STFT frames/sec through K-means+tokenize, n_mels=64, vocab=8192.
-Workload: configs[3] ("unbal_train 200k-clip subset, n_mels=64, vocab_size=8192, 8 GPUs") cut into
-its eight per-GPU shards -- 22 500 train + 2 500 validation synthetic 10 s clips per GPU (weak
-scaling: N GPUs process N shards; N = 8 is configs[3] itself).  One step = one full pass of the hot
-path over the resident waveforms: fused log-mel (frame-major, unit rows) -> one FAISS-style
-Kmeans.train per batch of 10 000 files (20 Lloyd iterations on a 2 097 152-row subsample, warm
-started) -> centroid normalisation -> nearest-centroid tokens for every frame.  Inputs are in HBM
-before the timed region starts.  Rank 0 prints ONE JSON line.
+Default workload (--config 3): configs[3] ("unbal_train 200k-clip subset, n_mels=64, vocab_size=8192, 8 GPUs")
+cut into its eight per-GPU shards -- 22 500 train + 2 500 validation synthetic 10 s clips per GPU (weak
+scaling: N GPUs process N shards; N = 8 is configs[3] itself).  --config 1 / 2 run BASELINE.json's
+single-GPU configs[1] (19 944 + 2 216 clips, n_mels=64, vocab 500) and configs[2] (same clips, n_mels=128,
+vocab 8192) instead; their lines are committed under profiles/, the driver's line stays on --config 3.
+
+One step = one full pass of the hot path over the resident waveforms, exactly what one run of the
+reference's three stages computes: fused log-mel (frame-major, unit rows) -> one FAISS-style Kmeans.train
+per batch of 10 000 files (subsample permutation, 20 Lloyd iterations on 256*k rows, warm started) ->
+centroid normalisation -> nearest-centroid tokens for every frame.  Nothing is carried from one step to
+the next (the subsample permutation is computed inside every step, on the device).  Inputs are in HBM before
+the timed region starts.  Rank 0 prints ONE JSON line.
+
+Outside the timed region the same step is run once more with every acceleration off (dense fp32 sweeps):
+`dense_floor` is its rate -- what the path does on data that defeats the pruning -- and `verified` says its
+tokens and centroids equal the timed configuration's bit for bit.
 """
 from __future__ import annotations
 
@@ -31,8 +40,16 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PEAK_F16_MFMA_TFLOPS = 2516.8  # same guide: BF16/F16 MFMA ~2.5 PF dense = 16 x the fp32 MFMA rate
+# /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_MFMA_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MFMA_TFLOPS = 2516.8  # BF16/F16 MFMA, dense = 16 x the fp32 MFMA rate
+PEAK_HBM_GBS = 8000.0          # HBM3E
+
+CONFIGS = {
+    1: dict(name="configs[1]", train=19944, val=2216, n_mels=64, vocab=500),
+    2: dict(name="configs[2]", train=19944, val=2216, n_mels=128, vocab=8192),
+    3: dict(name="configs[3] per-GPU shard", train=22500, val=2500, n_mels=64, vocab=8192),
+}
 
 
 def cpu_baseline(n_mels, vocab, L, hop, seed, clips, niter):
@@ -59,7 +76,7 @@ def cpu_baseline(n_mels, vocab, L, hop, seed, clips, niter):
         "cores": oracle.num_threads(),
         "kind": "port",
         "sample": (f"{clips} clips ({frames} frames) of the same synthetic stream: log-mel, one Kmeans.train "
-                   f"(k={vocab}, niter={niter} ~ the full job's 2.9 Lloyd point-iterations per frame), tokenise; "
+                   f"(k={vocab}, niter={niter}), tokenise; "
                    f"seconds: logmel {t1 - t0:.2f}, kmeans {t2 - t1:.2f}, tokenise {t3 - t2:.2f}; "
                    f"host has {os.cpu_count()} logical cores"),
     }
@@ -70,18 +87,25 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--train-clips", type=int, default=22500, help="per GPU")
-    ap.add_argument("--val-clips", type=int, default=2500, help="per GPU")
-    ap.add_argument("--n-mels", type=int, default=64)
-    ap.add_argument("--vocab", type=int, default=8192)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS), help="BASELINE.json configs[i]")
+    ap.add_argument("--train-clips", type=int, default=None, help="per GPU (default: the config's)")
+    ap.add_argument("--val-clips", type=int, default=None, help="per GPU")
+    ap.add_argument("--n-mels", type=int, default=None)
+    ap.add_argument("--vocab", type=int, default=None)
     ap.add_argument("--niter", type=int, default=20)
     ap.add_argument("--clip-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dense-floor", action="store_true", help="skip the untimed dense run (dense_floor / verified = null)")
     ap.add_argument("--cpu-clips", type=int, default=256)
     ap.add_argument("--host-waves", action="store_true",
                     help="also time DevicePipeline.run_streaming on pinned host copies of the same waveforms and report it "
                          "as pcie_inclusive (never `value`)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    n_tr = cfg["train"] if args.train_clips is None else args.train_clips
+    n_va = cfg["val"] if args.val_clips is None else args.val_clips
+    n_mels = cfg["n_mels"] if args.n_mels is None else args.n_mels
+    vocab = cfg["vocab"] if args.vocab is None else args.vocab
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -90,23 +114,28 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
-    assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (no CPU fallback)"
     # Rehearsal switches (not used by the driver): AT_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
     # AT_BENCH_BACKEND=gloo exchanges through the host, so the N > 1 code path can be exercised on a
     # one-GPU box.  The real multi-GPU run is one rank per GPU over RCCL ("nccl").
     if os.environ.get("AT_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
     backend = os.environ.get("AT_BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
     dist = None
+    comm = None
     if world > 1:
+        # the process group comes first: RCCL binds this rank to its device before anything else touches a GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        assert torch.cuda.device_count() > local_rank, f"rank {rank}: no device {local_rank}"
+        torch.cuda.set_device(local_rank)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        comm = {"backend": dist.get_backend(), "ranks": dist.get_world_size()}
+    assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
 
     from audio_tokens_amd.backend import default_backend
     from audio_tokens_amd.pipeline import DevicePipeline
@@ -117,23 +146,29 @@ def main():
     L = int(round(args.clip_seconds * sr))
     T = be.num_frames(L, hop)
     seed = 4242
-    n_tr, n_va = args.train_clips, args.val_clips
     # global clip ids: train clips first (rank-major inside every 10 000-file batch is implied by
     # the sharded Kmeans), then validation clips; any rank can generate its own shard
     wave_tr = synth_clips(n_tr, L=L, seed=seed, first_clip=rank * n_tr, device=device)
     wave_va = synth_clips(n_va, L=L, seed=seed, first_clip=world * n_tr + rank * n_va, device=device)
 
-    pipe = DevicePipeline(n_mels=args.n_mels, vocab_size=args.vocab, niter=args.niter, sample_rate=sr,
-                          n_fft=n_fft, hop_length=hop, clustering_batch_size=10000,
-                          distributed=world > 1, backend=be)
+    def make_pipe(prune=True):
+        return DevicePipeline(n_mels=n_mels, vocab_size=vocab, niter=args.niter, sample_rate=sr, n_fft=n_fft,
+                              hop_length=hop, clustering_batch_size=10000, distributed=world > 1, backend=be, prune=prune)
+
+    pipe = make_pipe()
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    warm_ms = []
     for _ in range(args.warmup):
+        barrier()
+        t0 = time.perf_counter()
         res = pipe.run(wave_tr, wave_va)
+        barrier()
+        warm_ms.append((time.perf_counter() - t0) * 1e3)
     be.assign_trace = []
     be.prune_stats(reset=True)
     be.filter_stats(reset=True)
@@ -156,121 +191,127 @@ def main():
     frames_per_step = (n_tr + n_va) * T * world
     value = frames_per_step * args.steps / elapsed
 
-    # Roofline of the dominant kernel, from HIP events recorded on the launch stream around every
-    # nearest-centroid launch of the timed steps.  Kinds: "pruned" = assign_mfma_pruned_kernel in exact
-    # mode (Lloyd iterations 2..20, plus the last stage of the unguided search used by iteration 1 and
-    # by tokenise); "coarse" = the same kernel as guess generator; "plain" = assign_mfma_kernel (here:
-    # rows against the 256 group means); "hinted" = assign_mfma_hinted_kernel (only when pruning is
-    # off).  ALGORITHMIC flops = 2*d*k per row for the exact kinds -- what IndexFlatL2.search must
-    # evaluate; the pruned sweep provably (bit-exact results) skips most 32x32 accumulators, so its
-    # algorithmic rate can exceed the MFMA peak.  executed_* prices only the accumulators computed.
+    # ---- the same step with every acceleration off: the floor, and the check of what was timed -------------
+    dense_floor, verified = None, None
+    if not args.no_dense_floor:
+        dpipe = make_pipe(prune=False)
+        barrier()
+        t0 = time.perf_counter()
+        dres = dpipe.run(wave_tr, wave_va)
+        barrier()
+        dt = time.perf_counter() - t0
+        same = (torch.equal(res.centroids.view(torch.int32), dres.centroids.view(torch.int32))
+                and torch.equal(res.tokens_train, dres.tokens_train) and torch.equal(res.tokens_val, dres.tokens_val))
+        if dist is not None:
+            flags = torch.tensor([dt, 0.0 if same else 1.0], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+            dt, same = float(flags[0].item()), float(flags[1].item()) == 0.0
+        verified = bool(same)
+        dense_floor = {"value": frames_per_step / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
+                       "note": "one untimed step with pruning, the fp16 filter and the guess generators off: plain dense fp32 MFMA "
+                               "sweeps (assign_mfma_kernel / assign_mfma_hinted_kernel); `verified` compares its centroids and "
+                               "tokens with the timed configuration's, bit for bit"}
+        del dres
+
+    # ---- roofline of the dominant kernel, from HIP events recorded on the launch stream ----------------------
+    # Kinds: "logmel" = logmel_kernel launches; "pruned" = at_assign_pruned_f32 exact calls (the fp16-filter sweep
+    # + redo); "coarse" = guess generators; "plain" = assign_mfma_kernel (dense); "hinted" = assign_mfma_hinted_kernel.
     def agg(kind):
         sel = [t for t in trace if t[0] == kind]
-        fl = sum(2.0 * n * d * k for (_, n, d, k, _, _) in sel)
         ms = sum(e0.elapsed_time(e1) for (_, _, _, _, e0, e1) in sel)
-        return {"launches": len(sel), "flop": fl, "ms": ms}
+        return {"launches": len(sel), "ms": ms, "sel": sel}
 
-    kinds = {kd: agg(kd) for kd in ("pruned", "coarse", "plain", "hinted")}
+    kinds = {kd: agg(kd) for kd in ("logmel", "pruned", "coarse", "plain", "hinted")}
     filtered = f_sweeps > 0
-    names = {"pruned": ("at_assign_pruned_f32 exact call: assign_f16filter_kernel<64,2,false,true,3> + exact_dist_todo_kernel + fp32 redo "
-                        "of the listed rows (exact_rows_kernel<64>)") if filtered
-             else "assign_mfma_pruned_reg_kernel<64,2> (at_assign_pruned_f32, exact mode)",
-             "coarse": ("assign_f16filter_kernel<64,4,true,false>" if filtered else "assign_mfma_pruned_reg_kernel<64,2>") + " (guess generator)",
-             "plain": "assign_mfma_kernel<64,2,4,DMA,2> (at_assign_f32)",
-             "hinted": "assign_mfma_hinted_kernel<64,2,4> (at_assign_hinted_f32)"}
-    dom = max(kinds, key=lambda kd: kinds[kd]["ms"])
+    if filtered:   # the stage-1 kernel of the exact calls is timed by the library's own events around that kernel alone
+        kinds["pruned"]["kernel_ms"] = f_ms
+    dom = max(kinds, key=lambda kd: kinds[kd].get("kernel_ms", kinds[kd]["ms"]))
     D = kinds[dom]
-    exec_frac = needed / total if total else None
-    traffic = None
-    tfile = ROOT / "profiles" / "assign_traffic.json"
-    if tfile.exists():
-        try:
-            tj = json.loads(tfile.read_text())
-            want = "assign_f16filter_kernel" if (filtered and dom == "pruned") else "assign_mfma_pruned_reg_kernel"
-            traffic = tj.get("hbm_bytes_per_launch") if want in tj.get("kernel", "") else None
-        except Exception:
-            traffic = None
-    ms_all = sum(v["ms"] for v in kinds.values())
-    per_kind = {kd: {"kernel": names[kd], "launches": v["launches"], "avg_launch_ms": v["ms"] / max(1, v["launches"]),
-                     "algorithmic_tflops": v["flop"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0}
-                for kd, v in kinds.items() if v["launches"]}
-    if filtered and dom == "pruned":
-        # Dominant kernel = the fp16-split filter sweep (stage 1 of every exact call), timed by HIP events
-        # the library records on the launch stream around that kernel alone (at_filter_stats).  Its
-        # algorithmic work = 2*d*k flop for every row it settles (rows it lists for the fp32 redo are
-        # not credited).  It issues v_mfma_f32_32x32x16_f16: three fp16 MFMAs per fp32 one, on the
-        # accumulators the exact pruning bound leaves.
-        rows_settled = f_rows - f_listed
-        flop = 2.0 * args.n_mels * args.vocab * rows_settled
-        achieved = flop / (f_ms * 1e-3) / 1e12 if f_ms > 0 else 0.0
-        ns = args.n_mels // 16
+    step_share = lambda ms: (ms * 1e-3) / elapsed if elapsed > 0 else None   # noqa: E731
+    traffic_file = ROOT / "profiles" / "kernel_traffic.json"
+    traffic_tab = json.loads(traffic_file.read_text()) if traffic_file.exists() else {}
+
+    def traffic_of(key):
+        t = traffic_tab.get(key)
+        return t.get("hbm_bytes_per_launch") if isinstance(t, dict) else None
+
+    if dom == "logmel":
+        frames = sum(n for (_, n, _, _, _, _) in D["sel"])
+        byts = frames * (hop * 4 + n_mels * 4)
+        achieved = byts / (D["ms"] * 1e-3) / 1e9
+        kname = "logmel_kernel<true>"
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
+                    "traffic": traffic_of(f"logmel_d{n_mels}"), "kernel": kname, "launches": D["launches"],
+                    "avg_launch_ms": D["ms"] / max(1, D["launches"]), "bytes_per_launch": byts / max(1, D["launches"]),
+                    "share_of_step_time": step_share(D["ms"]),
+                    "note": "algorithmic bytes = (hop*4 + n_mels*4) per frame: every sample read once, every output written once"}
+    elif dom == "pruned" and filtered:
+        # Dominant kernel = the fp16-split filter sweep (stage 1 of every exact call).  `frac` prices the fp16 MFMA
+        # instructions the kernel ISSUED (counted by the kernel itself per 32x32 tile) against the dense fp16 MFMA
+        # peak -- a real fraction of a real roof.  The contract's dense work (2*d*k flop per row) divided by the same
+        # time is reported separately as algorithmic_rate_vs_dense_fp32_peak: it exceeds 1 because a rounding-safe
+        # bound skips most tiles and the rest are decided in fp16, with bit-identical results (`verified`).
+        ns = n_mels // 16
         mfma_issued = f_tiles * ns + f_refined * 2 * ns            # v_mfma_f32_32x32x16_f16 instructions
-        exec_f16 = mfma_issued * 32768.0 / (f_ms * 1e-3) / 1e12 if f_ms > 0 else None
-        roofline = {
-            "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-            "kernel": "assign_f16filter_kernel<64,2,false,true,3> (stage 1 of at_assign_pruned_f32, exact mode)",
-            "launches": f_sweeps, "avg_launch_ms": f_ms / f_sweeps, "flop_per_launch": flop / f_sweeps,
-            "share_of_step_time": (f_ms * 1e-3) / elapsed if elapsed > 0 else None,
-            "rows_listed_for_fp32_redo_fraction": f_listed / f_rows if f_rows else None,
-            "accumulators_computed_fraction": exec_frac,
-            "tiles_refined_with_lo_products_fraction": f_refined / f_tiles if f_tiles else None,
-            "executed_mfma_dtype": "f16 (fp32 accumulate)", "executed_tflops": exec_f16,
-            "executed_peak": PEAK_F16_MFMA_TFLOPS,
-            "executed_frac": exec_f16 / PEAK_F16_MFMA_TFLOPS if exec_f16 is not None else None,
-            "exact_call": {"kernel": names["pruned"], "launches": D["launches"],
-                           "avg_ms": D["ms"] / max(1, D["launches"]),
-                           "algorithmic_tflops": D["flop"] / (D["ms"] * 1e-3) / 1e12 if D["ms"] > 0 else 0.0,
-                           "share_of_step_time": (D["ms"] * 1e-3) / elapsed if elapsed > 0 else None},
-            "note": ("achieved/frac are ALGORITHMIC fp32 flop (2*d*k per row = the dense IndexFlatL2 search the contract "
-                     "specifies) against the fp32 MFMA peak; > 1 because (a) a rounding-safe triangle-inequality bound skips "
-                     "most 32x32 accumulators and (b) the surviving ones are evaluated with fp16 MFMAs (hi*hi first, the two lo "
-                     "products only for tiles that can matter) whose error is bounded a priori, a row being accepted only when "
-                     "its runner-up is provably out of reach of the fp32 contract; the other rows are redone in fp32.  ids/dist/centroids are bit-identical to the dense fp32 "
-                     "sweep (tests/test_gpu_ops.py::test_assign_pruned_is_exact, test_filter_*).  executed_* prices the "
-                     "fp16 MFMA flop actually issued against the dense fp16 peak.  The dense fp32 kernel "
-                     "(assign_mfma_kernel) runs at 132 TFLOP/s = 84 % of the fp32 peak, see profiles/."),
-            "all_nearest_centroid_launches": {"share_of_step_time": (ms_all * 1e-3) / elapsed if elapsed > 0 else None,
-                                              **per_kind},
-        }
+        exec_tf = mfma_issued * 32768.0 / (f_ms * 1e-3) / 1e12 if f_ms > 0 else 0.0
+        rows_settled = f_rows - f_listed
+        alg_tf = 2.0 * n_mels * vocab * rows_settled / (f_ms * 1e-3) / 1e12 if f_ms > 0 else 0.0
+        wps = "3" if n_mels == 64 else "2"
+        key = f"filter_d{n_mels}"
+        tr = traffic_of(key)
+        avg_ms = f_ms / f_sweeps
+        roofline = {"bound": "mfma", "achieved": exec_tf, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": exec_tf / PEAK_F16_MFMA_TFLOPS, "traffic": tr,
+                    "kernel": f"assign_f16filter_kernel<{n_mels},...> (stage 1 of at_assign_pruned_f32 exact calls; Lloyd sweeps at {wps} "
+                              "waves/SIMD and the long tokenise sweeps)",
+                    "launches": f_sweeps, "avg_launch_ms": avg_ms, "flop_per_launch": mfma_issued * 32768.0 / f_sweeps,
+                    "mfma_dtype": "f16 inputs, f32 accumulate (v_mfma_f32_32x32x16_f16)",
+                    "share_of_step_time": step_share(f_ms),
+                    "hbm_frac": (tr / (traffic_tab[key].get("launch_ms", avg_ms) * 1e-3) / 1e9 / PEAK_HBM_GBS) if tr else None,
+                    "algorithmic_rate_vs_dense_fp32_peak": alg_tf / PEAK_F32_MFMA_TFLOPS,
+                    "algorithmic_tflops": alg_tf,
+                    "accumulators_computed_fraction": needed / total if total else None,
+                    "tiles_refined_with_lo_products_fraction": f_refined / f_tiles if f_tiles else None,
+                    "rows_listed_for_fp32_redo_fraction": f_listed / f_rows if f_rows else None,
+                    "exact_call": {"launches": D["launches"], "avg_ms": D["ms"] / max(1, D["launches"]),
+                                   "share_of_step_time": step_share(D["ms"])},
+                    "note": "frac = issued fp16 MFMA flop / dense fp16 MFMA peak (the kernel is latency-bound: see DESIGN.md section 5); "
+                            "hbm_frac = PMC bytes per launch / launch time / 8 TB/s on the Lloyd-sweep form of the kernel"}
     else:
-        achieved = D["flop"] / (D["ms"] * 1e-3) / 1e12 if D["ms"] > 0 else 0.0
-        roofline = {
-            "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-            "kernel": names[dom], "launches": D["launches"],
-            "avg_launch_ms": D["ms"] / max(1, D["launches"]), "flop_per_launch": D["flop"] / max(1, D["launches"]),
-            "share_of_step_time": (D["ms"] * 1e-3) / elapsed if elapsed > 0 else None,
-            # rocprofv3 reports one average per kernel symbol; the pruned sweep kernel also runs in guess-generator
-            # mode ("coarse"), so this is the figure its average is to be compared with
-            "kernel_avg_launch_ms_all_modes": ((kinds["pruned"]["ms"] + kinds["coarse"]["ms"]) /
-                                               max(1, kinds["pruned"]["launches"] + kinds["coarse"]["launches"]))
-            if dom == "pruned" else None,
-            "accumulators_computed_fraction": exec_frac,
-            "executed_tflops": achieved * exec_frac if (exec_frac is not None and dom == "pruned") else None,
-            "executed_frac": (achieved * exec_frac / PEAK_F32_MFMA_TFLOPS) if (exec_frac is not None and dom == "pruned") else None,
-            "note": ("achieved/frac are algorithmic (2*d*k flop per row, the dense IndexFlatL2 search): > 1 means the exact "
-                     "pruned sweep skipped accumulators that a rounding-safe triangle-inequality bound rules out; results are "
-                     "bit-identical to the dense sweep (tests/test_gpu_ops.py::test_assign_pruned_is_exact). executed_* counts "
-                     "only computed accumulators; the dense kernel (assign_mfma_kernel) runs at 132 TFLOP/s = 84 % of peak, "
-                     "see profiles/."),
-            "all_nearest_centroid_launches": {"share_of_step_time": (ms_all * 1e-3) / elapsed if elapsed > 0 else None,
-                                              **per_kind},
-        }
+        flop = sum(2.0 * n * d * k for (_, n, d, k, _, _) in D["sel"])
+        achieved = flop / (D["ms"] * 1e-3) / 1e12 if D["ms"] > 0 else 0.0
+        kname = {"plain": f"assign_mfma_kernel<{n_mels},...> (at_assign_f32, dense)",
+                 "hinted": f"assign_mfma_hinted_kernel<{n_mels},...> (at_assign_hinted_f32, dense)",
+                 "pruned": f"assign_mfma_pruned_reg_kernel<{n_mels},2> (exact pruned fp32 sweep)",
+                 "coarse": "guess generator"}[dom]
+        executed = achieved * (needed / total) if (dom == "pruned" and total) else achieved
+        roofline = {"bound": "mfma", "achieved": executed, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": executed / PEAK_F32_MFMA_TFLOPS, "traffic": traffic_of(f"{dom}_d{n_mels}"), "kernel": kname,
+                    "launches": D["launches"], "avg_launch_ms": D["ms"] / max(1, D["launches"]),
+                    "flop_per_launch": flop / max(1, D["launches"]), "share_of_step_time": step_share(D["ms"]),
+                    "algorithmic_rate_vs_dense_fp32_peak": achieved / PEAK_F32_MFMA_TFLOPS,
+                    "note": "2*d*k flop per row per launch (the dense IndexFlatL2 search), fp32 MFMA"}
+    roofline["all_timed_kernel_classes"] = {
+        kd: {"launches": v["launches"], "ms_per_step": v["ms"] / args.steps, "share_of_step_time": step_share(v["ms"])}
+        for kd, v in kinds.items() if v["launches"]}
 
     out = {
-        "metric": "STFT frames/sec through K-means+tokenize, n_mels=64 vocab=8192",
+        "metric": f"STFT frames/sec through K-means+tokenize, n_mels={n_mels} vocab={vocab}",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": (f"configs[3] per-GPU shard x{world}: {n_tr}+{n_va} clips/GPU of {args.clip_seconds:g} s @22.05 kHz "
-                         f"({(n_tr + n_va) * T} frames/GPU), n_mels={args.n_mels}, vocab_size={args.vocab}, niter={args.niter}, "
-                         f"k-means batches of 10000 files on a {min(256 * args.vocab, 10000 * T)}-row subsample"),
+            "workload": (f"{cfg['name']} x{world}: {n_tr}+{n_va} clips/GPU of {args.clip_seconds:g} s @22.05 kHz "
+                         f"({(n_tr + n_va) * T} frames/GPU), n_mels={n_mels}, vocab_size={vocab}, niter={args.niter}, "
+                         f"k-means batches of 10000 files on a {min(256 * vocab, 10000 * T)}-row subsample"),
             "frames_per_step": frames_per_step, "parallelism": f"dp{world}",
         },
         "stage_seconds": stage,
+        "warmup_step_ms": warm_ms,
+        "verified": verified,
+        "dense_floor": dense_floor,
         "roofline": roofline,
+        "comm": comm,
     }
     if args.host_waves:
         host_tr, host_va = wave_tr.cpu().pin_memory(), wave_va.cpu().pin_memory()
@@ -284,7 +325,7 @@ def main():
                                  "note": "waveforms in pinned host memory, streamed in 5000-clip chunks; frames kept only per "
                                          "k-means batch and recomputed for tokenise; tokens returned to the host"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.n_mels, args.vocab, L, hop, seed, args.cpu_clips, niter=3)
+        out["cpu_baseline"] = cpu_baseline(n_mels, vocab, L, hop, seed, args.cpu_clips, niter=3)
     else:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -165,3 +165,26 @@ def test_full_size_properties(be):
     assert float(counts.sum()) == n
     tot = part[: k * d].view(k, d).double().sum(0)
     assert float((tot - x.double().sum(0)).abs().max()) < 1e-2
+
+
+def test_logmel_user_filterbanks_are_compared_by_value(be, oracle):
+    """two different filterbanks of the same shape back to back -- the second one lands at the
+    address the allocator just freed -- and one rewritten in place must each produce their own spectrogram."""
+    g = np.load(G / "logmel.npz")
+    wave = torch.from_numpy(g["wave"]).to(be.device)
+    fb_a = g["fb_64"].copy()
+    fb_b = fb_a[:, ::-1].copy()                       # same shape, different values
+    def run(fb):
+        t = torch.from_numpy(fb).to(be.device)        # a fresh temporary per call, as backend.logmel does for numpy
+        out = be.logmel(wave, n_mels=64, fb=t)
+        del t
+        return out
+
+    a1, b1, a2 = run(fb_a), run(fb_b), run(fb_a)
+    assert torch.equal(a1, a2) and not torch.equal(a1, b1)
+    assert torch.equal(b1, a1.flip(1))                # mel axis reversed with the filterbank
+    t = torch.from_numpy(fb_a).to(be.device)
+    x1 = be.logmel(wave, n_mels=64, fb=t)
+    t.copy_(torch.from_numpy(fb_b))                   # rewritten in place: same address, new values
+    x2 = be.logmel(wave, n_mels=64, fb=t)
+    assert torch.equal(x1, a1) and torch.equal(x2, b1)

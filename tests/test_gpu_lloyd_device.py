@@ -109,7 +109,8 @@ def test_kmeans_train_without_host_round_trips_matches_oracle(be, oracle, sync):
     assert np.array_equal(bits(km.centroids), bits(r.centroids))
     assert [s["nsplit"] for s in km.iteration_stats] == list(r.nsplit)
     assert sum(r.nsplit) > 0, "the case is meant to exercise split_clusters"
-    np.testing.assert_allclose(km.obj, r.obj, rtol=2e-6)
+    # (the objective is a statistic: summed in double on the device, sequentially in float by faiss / the oracle)
+    np.testing.assert_allclose(km.obj, r.obj, rtol=2e-5)
     np.testing.assert_allclose([s["imbalance_factor"] for s in km.iteration_stats], r.imbalance, rtol=1e-12)
     assert (loss is None) == (not sync)
     x2 = oracle.l2norm_rows(rng.standard_normal((30000, d)).astype(np.float32))
