@@ -61,6 +61,7 @@ SIGNATURES = {
     "at_centroid_accum_defer": (_i32, [_vp, _i32]),
     "at_centroid_accum_join": (_i32, [_vp, _vp]),
     "at_token_histogram_i64": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "at_token_stats_f64": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

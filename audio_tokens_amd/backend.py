@@ -226,6 +226,18 @@ class HipBackend(HostHelpers):
             _lib.check(self.lib.at_token_histogram_i64(self.ctx.handle, _ptr(ids), ids.numel(), k, _ptr(counts), self._stream()))
         return counts
 
+    def token_stats(self, counts):
+        """counts: int64 [k] device histogram -> (sorted_counts int64 [k] descending, sorted_tokens int32 [k],
+        stats float64 [8]: total, unique, ranks below 80 % cumulative share, slope, intercept, r, points fitted), all on
+        the device (at_token_stats_f64)."""
+        assert counts.dtype == torch.int64 and counts.is_contiguous() and counts.device == self.device
+        k = counts.numel()
+        sc, stok = self.empty((k,), torch.int64), self.empty((k,), torch.int32)
+        stats = self.empty((8,), torch.float64)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_token_stats_f64(self.ctx.handle, _ptr(counts), k, _ptr(sc), _ptr(stok), _ptr(stats), self._stream()))
+        return sc, stok, stats
+
     def l2norm_rows(self, x, out=None) -> torch.Tensor:
         x = self._f32(x)
         assert x.dim() == 2

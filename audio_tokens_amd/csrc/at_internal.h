@@ -42,6 +42,8 @@ enum at_ws_slot {
     WS_PERM_PREV,
     WS_PERM_LAST,
     WS_SPLIT_LIST,     // at_split_clusters_f32: the clusters that came out empty
+    WS_TSTAT_IOTA,     // at_token_stats_f64: token ids before the sort, rocprim temp storage
+    WS_TSTAT_TMP,
     WS_NSLOTS
 };
 

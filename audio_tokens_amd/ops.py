@@ -374,12 +374,12 @@ class Kmeans:
             be.lloyd_stats(hassign, parts, k, d, stats_dev[it])
             be.split_clusters_device(hassign, cent, ns, nsplit_dev[it:it + 1])
             tp = lap("exchange+finalize+split", tp)
-            if self.verbose:
-                st = self._read_stats(stats_dev[:it + 1], nsplit_dev[:it + 1], t0)[-1]
-                print(f"  Iteration {it} ({st['time']:.2f} s, search {st['time_search']:.2f} s): "
-                      f"objective={st['obj']:g} imbalance={st['imbalance_factor']:.3f} nsplit={st['nsplit']}", flush=True)
         self._last_assign = ids
         self._stats_pending = (stats_dev[:niter], nsplit_dev[:niter], t0)
+        if self.verbose:   # faiss' per-iteration lines, printed once the iterations are through (no wait inside the loop)
+            for it, st in enumerate(self.iteration_stats):
+                print(f"  Iteration {it} ({st['time']:.2f} s, search {st['time_search']:.2f} s): "
+                      f"objective={st['obj']:g} imbalance={st['imbalance_factor']:.3f} nsplit={st['nsplit']}", flush=True)
         if prune:
             # (the late one was submitted several iterations ago: done, or about to be)
             if regrouping is not None and (regrouping.done() or regrouping_is_late):

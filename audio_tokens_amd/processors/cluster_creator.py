@@ -53,16 +53,21 @@ class ClusterCreator:
             verbose=True,
             gpu=self.gpu,
         )
-        # the next batch of files is read while this one trains (same batches, same order)
-        for i, batch in enumerate(prefetch(self._batch_generator(self.config.clustering_batch_size))):
-            batch = self.normalize_vectors(batch)
+        # The next batch of files is read while this one trains (same batches, same order).  A batch crosses to
+        # the device ONCE: convolution (if any), row normalisation and the training run there, and the warm start
+        # takes the previous centroids where they already are.
+        be = kmeans.backend
+        for i, batch in enumerate(prefetch(self._frame_batches(self.config.clustering_batch_size))):
+            batch = be._f32(batch)
+            if self.config.use_convolution:
+                batch = self._convolve_device(batch)
+            batch = normalize_rows(batch, be)
             if i == 0:
                 kmeans.train(batch)
             else:
-                kmeans.train(batch, init_centroids=kmeans.centroids)
+                kmeans.train(batch, init_centroids=kmeans.centroids_device)
 
-        centroids = kmeans.centroids
-        centroids = self.normalize_vectors(centroids)
+        centroids = be.to_host(normalize_rows(kmeans.centroids_device, be))
         kmeans.lend_grouping(centroids)   # (a tokeniser in this process starts from this grouping)
         self.logger.info(f"Centroids shape: {centroids.shape}")
         Path(self.config.centroids_path).parent.mkdir(parents=True, exist_ok=True)
@@ -73,34 +78,32 @@ class ClusterCreator:
         """vectors / (||vectors||_2 + 1e-10) row-wise; same bits as the reference's numpy lines."""
         return normalize_rows(vectors)
 
-    def apply_convolution(self, time_slice_batch):
-        time_slice_batch = np.array(time_slice_batch)
-        time_slice_batch = torch.tensor(time_slice_batch, device=self.device).float().unsqueeze(1)
-        conv_output = self.conv(time_slice_batch)
-        return (
-            conv_output.transpose(1, 2)
-            .reshape(-1, self.config.num_kernels * self.config.n_mels)
-            .cpu()
-            .detach()
-            .numpy()
-        )
+    def _convolve_device(self, frames, chunk=1 << 20):
+        """frames [n, n_mels] (device) -> [n, num_kernels * n_mels] (device), feature = mel * num_kernels + kernel."""
+        out = torch.empty((frames.shape[0], self.config.num_kernels * self.config.n_mels), dtype=torch.float32,
+                          device=frames.device)
+        with torch.no_grad():
+            for r0 in range(0, frames.shape[0], chunk):
+                y = self.conv(frames[r0:r0 + chunk].unsqueeze(1))
+                out[r0:r0 + chunk] = y.transpose(1, 2).reshape(y.shape[0], -1)
+        return out
 
-    def _batch_generator(self, batch_size):
+    def apply_convolution(self, time_slice_batch):
+        frames = torch.as_tensor(np.asarray(time_slice_batch), device=self.device).float()
+        return self._convolve_device(frames).cpu().numpy()
+
+    def _frame_batches(self, batch_size):
+        """Host frame matrices [sum T, n_mels] float32, one per `batch_size` spectrogram files."""
         spec_dir = Path(self.config.source_spec_path) / "train"
         # the reference takes Path.glob's order (file-system dependent); sorted is one such order
         files = sorted(spec_dir.glob("*.npy"))
-
         for i in tqdm(range(0, len(files), batch_size)):
-            batch_files = files[i:i + batch_size]
-            batch_data = []
-            for file in batch_files:
-                spec = np.load(file)
-                batch_data.append(spec.T)
-            all_time_slices = np.concatenate(batch_data, axis=0)
-            if self.config.use_convolution:
-                yield self.apply_convolution(all_time_slices)
-            else:
-                yield all_time_slices.astype(np.float32)
+            yield np.concatenate([np.load(f).T for f in files[i:i + batch_size]], axis=0).astype(np.float32, copy=False)
+
+    def _batch_generator(self, batch_size):
+        """The reference's generator (cluster_creator.py:83-102): numpy batches, convolved if configured."""
+        for frames in self._frame_batches(batch_size):
+            yield self.apply_convolution(frames) if self.config.use_convolution else frames
 
     def visualize_centroids(self, centroids):
         try:

@@ -3,13 +3,13 @@ danavery/audio-tokens) on the MI355X nearest-centroid kernel.
 
 Same constructor, methods and artefacts (tokenized_audio/{train,validation}/<stem>.npy: int64 [T]).
 `faiss.IndexFlatL2` is audio_tokens_amd.ops.IndexFlatL2; the per-batch sequence (load, transpose,
-concatenate, normalise rows, search(.,1), slice per file, save) is the reference's.  The token
-statistics / plots at the end of the train split are reporting: the counts are computed on the
-device and the plots are drawn only if matplotlib is importable.
+concatenate, normalise rows, search(.,1), slice per file, save) is the reference's.  A batch
+crosses to the device once (convolution, row normalisation and the search run there); the token
+statistics at the end of the train split are computed on the device from a histogram accumulated while
+tokenising, and the plots are drawn only if matplotlib is importable.
 """
 import logging
 import shutil
-from collections import Counter
 from pathlib import Path
 
 import numpy as np
@@ -41,6 +41,8 @@ class SpecTokenizer:
 
         if self.config.use_convolution:
             self.conv = self.create_convolution_layer()
+        self._hist = None                 # device histogram of the tokens written since setup_output_directory()
+        self.return_token_lists = True    # process_batch / tokenize_directory return tokens.tolist() like the reference
 
     def run(self):
         for split in ["train", "validation"]:
@@ -49,10 +51,15 @@ class SpecTokenizer:
 
             self.setup_output_directory(tokenized_dir)
             self.logger.info(f"Tokenizing {split} set: {source_spec_dir} --> {tokenized_dir}")
-            all_tokens = self.tokenize_directory(source_spec_dir, tokenized_dir)
+            # (run() needs no O(frames) Python list: the statistics come from the device histogram)
+            self.return_token_lists = False
+            try:
+                self.tokenize_directory(source_spec_dir, tokenized_dir)
+            finally:
+                self.return_token_lists = True
             if split == "train":
-                self.analyze_tokens(all_tokens)
-                self.plot_token_distribution(all_tokens)
+                self.analyze_tokens()
+                self.plot_token_distribution()
 
     def tokenize_directory(self, source_dir: Path, tokenized_dir: Path):
         all_tokens = []
@@ -76,15 +83,20 @@ class SpecTokenizer:
             batch_specs = [np.load(spec_file).T for spec_file in batch_files]
         batch_data = np.concatenate(batch_specs, axis=0)
 
-        if self.config.use_convolution:
-            processed_batch = self.apply_convolution(batch_data)
-        else:
-            processed_batch = batch_data.astype(np.float32)
+        # one host->device copy per batch; convolution, row normalisation and the search stay on the device
+        be = self.index.backend
+        processed_batch = None
+        if batch_data.size > 0:
+            processed_batch = be._f32(batch_data)
+            if self.config.use_convolution:
+                processed_batch = self._convolve_device(processed_batch)
 
-        if processed_batch is not None and processed_batch.size > 0:
-            processed_batch = self.normalize_vectors(processed_batch)
-            _, tokens = self.index.search(processed_batch, 1)
-            tokens = np.squeeze(tokens, 1)
+        if processed_batch is not None and processed_batch.numel() > 0:
+            processed_batch = normalize_rows(processed_batch, be)
+            tokens_dev, _ = self.index.assign(processed_batch, want_dist=False)
+            hist = be.token_histogram(tokens_dev, max(1, self.index.ntotal))
+            self._hist = hist if self._hist is None else self._hist + hist
+            tokens = be.to_host(tokens_dev)
 
             start = 0
             for spec_file, spec in zip(batch_files, batch_specs):
@@ -94,23 +106,27 @@ class SpecTokenizer:
                 np.save(output_file, file_tokens)
                 start = end
 
-            return tokens.tolist()
+            return tokens.tolist() if self.return_token_lists else []
 
         return []
+
+    def _convolve_device(self, frames, chunk=1 << 20):
+        """frames [n, n_mels] (device) -> [n, num_kernels * n_mels] (device): Conv1d along the mel axis, feature
+        index = mel * num_kernels + kernel, as the reference's transpose(1, 2).reshape lays it out."""
+        out = torch.empty((frames.shape[0], self.config.num_kernels * self.config.n_mels), dtype=torch.float32,
+                          device=frames.device)
+        with torch.no_grad():
+            for r0 in range(0, frames.shape[0], chunk):
+                y = self.conv(frames[r0:r0 + chunk].unsqueeze(1))
+                out[r0:r0 + chunk] = y.transpose(1, 2).reshape(y.shape[0], -1)
+        return out
 
     def apply_convolution(self, batch):
         if len(batch) == 0:
             self.logger.warning("Received empty batch for convolution")
             return None
-        batch_tensor = torch.tensor(batch, device=self.device).float().unsqueeze(1)
-        conv_output = self.conv(batch_tensor)
-        return (
-            conv_output.transpose(1, 2)
-            .reshape(-1, self.config.num_kernels * self.config.n_mels)
-            .cpu()
-            .detach()
-            .numpy()
-        )
+        batch_tensor = torch.as_tensor(np.asarray(batch), device=self.device).float()
+        return self._convolve_device(batch_tensor).cpu().numpy()
 
     @staticmethod
     def normalize_vectors(vectors):
@@ -119,6 +135,7 @@ class SpecTokenizer:
     def setup_output_directory(self, tokenized_dir):
         shutil.rmtree(tokenized_dir, ignore_errors=True)
         tokenized_dir.mkdir(parents=True)
+        self._hist = None
 
     def create_convolution_layer(self):
         return nn.Conv1d(
@@ -134,104 +151,115 @@ class SpecTokenizer:
         index.add(centroids)
         return index
 
-    # ---- reporting (host side, outside the accelerated path) --------------------------------
-    def _token_counts(self, all_tokens):
-        """Counter(all_tokens); long token lists are counted on the device (at_token_histogram_i64)
-        instead of in a Python loop.  Ties then come in ascending token id, not first-seen order."""
-        if len(all_tokens) < 1_000_000:
-            return Counter(all_tokens)
+    # ---- token statistics (reference: spec_tokenizer.py:129-240) ---------------------------------
+    # The reference keeps every token of the split as a Python int, counts them with a Counter, sorts the counts
+    # on the host and fits Zipf's law with scipy.  Here the histogram is accumulated on the device while the
+    # batches are tokenised (process_batch), at_token_stats_f64 sorts it and computes the cumulative-share rank and
+    # the log-log regression there, and only the k sorted counts come back -- for the prints and the optional plots.
+    # Differences in what is REPORTED (never in any artefact): equal counts rank in ascending token id (the
+    # reference: first-seen order), and the p-value / standard error of the fit, which the reference never prints,
+    # are not computed.
+    def token_statistics(self, all_tokens=None):
+        """-> dict(total, unique, tokens, frequencies, top_80, slope, intercept, r_value, n_fit) of `all_tokens`
+        (any int sequence / array / device tensor), or of the tokens seen since the last setup_output_directory()
+        when None.  tokens / frequencies: numpy, most frequent first, tokens that occur only."""
         be = self.index.backend
-        counts = be.to_host(be.token_histogram(np.asarray(all_tokens, dtype=np.int64), self.index.ntotal))
-        return Counter({int(t): int(c) for t, c in enumerate(counts) if c})
+        k = max(1, self.index.ntotal)
+        if all_tokens is None:
+            counts = self._hist if self._hist is not None else be.zeros((k,), torch.int64)
+        elif isinstance(all_tokens, torch.Tensor):
+            counts = be.token_histogram(all_tokens, k)
+        else:
+            counts = be.token_histogram(np.asarray(all_tokens, dtype=np.int64), k)
+        sc, stok, st = be.token_stats(counts)
+        st = be.to_host(st)
+        unique = int(st[1])
+        return dict(total=int(st[0]), unique=unique, tokens=be.to_host(stok)[:unique].astype(np.int64),
+                    frequencies=be.to_host(sc)[:unique], top_80=int(st[2]), slope=float(st[3]), intercept=float(st[4]),
+                    r_value=float(st[5]), n_fit=int(st[6]))
 
-    def analyze_tokens(self, all_tokens):
-        token_counts = self._token_counts(all_tokens)
-        self.logger.info(f"Total tokens: {len(all_tokens)}")
-        self.logger.info(f"Unique tokens: {len(token_counts)}")
-        if token_counts:
-            self.logger.info(f"Most common token: {token_counts.most_common(1)}")
-            self.logger.info(f"Least common token: {token_counts.most_common()[-1]}")
+    def analyze_tokens(self, all_tokens=None):
+        ts = self.token_statistics(all_tokens)
+        self.logger.info(f"Total tokens: {ts['total']}")
+        self.logger.info(f"Unique tokens: {ts['unique']}")
+        if ts["unique"]:
+            self.logger.info(f"Most common token: {[(int(ts['tokens'][0]), int(ts['frequencies'][0]))]}")
+            self.logger.info(f"Least common token: {(int(ts['tokens'][-1]), int(ts['frequencies'][-1]))}")
         plt = self._pyplot()
-        if plt is None or not token_counts:
-            return
+        if plt is None or not ts["unique"]:
+            return ts
         plt.figure(figsize=(12, 6))
-        plt.bar(token_counts.keys(), token_counts.values())
+        plt.bar(ts["tokens"], ts["frequencies"])
         plt.title("Distribution of Assigned Tokens")
         plt.xlabel("Token ID")
         plt.ylabel("Frequency")
         Path("output").mkdir(exist_ok=True)
         plt.savefig("output/token_distribution.png")
         plt.close()
+        return ts
 
-    def plot_token_distribution(self, all_tokens):
-        token_counts = self._token_counts(all_tokens)
-        if not token_counts:
-            return
-        sorted_counts = sorted(token_counts.items(), key=lambda x: x[1], reverse=True)
-        tokens, frequencies = zip(*sorted_counts)
-        ranks = range(1, len(tokens) + 1)
-
+    def plot_token_distribution(self, all_tokens=None):
+        ts = self.token_statistics(all_tokens)
+        if not ts["unique"]:
+            return ts
+        tokens, freq = ts["tokens"], ts["frequencies"]
         plt = self._pyplot()
         if plt is not None:
-            plt.figure(figsize=(15, 10))
-            plt.subplot(2, 1, 1)
-            plt.plot(ranks, frequencies)
-            plt.title("Distribution of Assigned Tokens (Sorted by Frequency)")
-            plt.xlabel("Token Rank")
-            plt.ylabel("Frequency")
-            plt.yscale("log")
-            plt.xscale("log")
-            plt.subplot(2, 1, 2)
-            plt.bar(ranks, frequencies)
-            plt.xlabel("Token Rank")
-            plt.ylabel("Frequency")
-            plt.tight_layout()
-            plt.savefig("correct_token_distribution.png")
-            plt.close()
+            ranks = np.arange(1, len(freq) + 1)
+            fig, (top, bottom) = plt.subplots(2, 1, figsize=(15, 10))
+            top.loglog(ranks, freq)
+            top.set_title("Distribution of Assigned Tokens (Sorted by Frequency)")
+            top.set_xlabel("Token Rank")
+            top.set_ylabel("Frequency")
+            bottom.bar(ranks, freq)
+            bottom.set_xlabel("Token Rank")
+            bottom.set_ylabel("Frequency")
+            fig.tight_layout()
+            fig.savefig("correct_token_distribution.png")
+            plt.close(fig)
+        print(f"Total unique tokens: {ts['unique']}")
+        print(f"Total token occurrences: {ts['total']}")
+        print(f"Most common token (rank 1): Token {tokens[0]} (used {freq[0]} times)")
+        print(f"Least common token (rank {len(tokens)}): Token {tokens[-1]} (used {freq[-1]} times)")
+        print(f"Top {ts['top_80'] + 1} tokens account for 80% of all token occurrences")
+        print(f"Frequency ratio between most and least common: {freq[0] / freq[-1]:.2f}")
+        self.analyze_zipf_and_tail(freq, _stats=ts)
+        return ts
 
-        total_tokens = sum(frequencies)
-        cumulative_freq = np.cumsum(frequencies) / total_tokens
-        top_80_percent = np.searchsorted(cumulative_freq, 0.8) + 1
-        print(f"Total unique tokens: {len(tokens)}")
-        print(f"Total token occurrences: {total_tokens}")
-        print(f"Most common token (rank 1): Token {tokens[0]} (used {frequencies[0]} times)")
-        print(f"Least common token (rank {len(tokens)}): Token {tokens[-1]} (used {frequencies[-1]} times)")
-        print(f"Top {top_80_percent} tokens account for 80% of all token occurrences")
-        print(f"Frequency ratio between most and least common: {frequencies[0] / frequencies[-1]:.2f}")
-        self.analyze_zipf_and_tail(frequencies)
-
-    def analyze_zipf_and_tail(self, frequencies):
-        from scipy import stats
-        ranks = np.arange(1, len(frequencies) + 1)
-        log_ranks = np.log(ranks)
-        log_frequencies = np.log(frequencies)
-        start_fit = int(0.1 * len(frequencies))
-        end_fit = int(0.9 * len(frequencies))
-        if end_fit - start_fit < 2:
-            return
-        slope, intercept, r_value, p_value, std_err = stats.linregress(
-            log_ranks[start_fit:end_fit], log_frequencies[start_fit:end_fit]
-        )
+    def analyze_zipf_and_tail(self, frequencies, _stats=None):
+        """frequencies: counts sorted descending (the reference's argument).  The fit and the tail are computed on
+        the device from them (a histogram that is already sorted stays as it is)."""
+        ts = _stats
+        if ts is None:
+            be = self.index.backend
+            f = np.ascontiguousarray(np.asarray(frequencies, dtype=np.int64))
+            sc, _, st = be.token_stats(be.from_host(f)) if f.size else (None, None, None)
+            if st is None:
+                return None
+            st = be.to_host(st)
+            ts = dict(unique=int(st[1]), frequencies=be.to_host(sc)[:int(st[1])], top_80=int(st[2]), slope=float(st[3]),
+                      intercept=float(st[4]), r_value=float(st[5]), n_fit=int(st[6]))
+        if ts["n_fit"] < 2:
+            return ts
         plt = self._pyplot()
         if plt is not None:
+            lr = np.log(np.arange(1, ts["unique"] + 1))
             plt.figure(figsize=(12, 8))
-            plt.scatter(log_ranks, log_frequencies, alpha=0.5, label="Observed")
-            plt.plot(log_ranks, intercept + slope * log_ranks, color="red", label=f"Fitted (slope = {slope:.2f})")
+            plt.scatter(lr, np.log(ts["frequencies"]), alpha=0.5, label="Observed")
+            plt.plot(lr, ts["intercept"] + ts["slope"] * lr, color="red", label=f"Fitted (slope = {ts['slope']:.2f})")
             plt.xlabel("Log Rank")
             plt.ylabel("Log Frequency")
             plt.title("Zipf's Law Analysis")
             plt.legend()
             plt.savefig("zipf_law_analysis.png")
             plt.close()
-
-        total_occurrences = sum(frequencies)
-        cumulative_freq = np.cumsum(frequencies) / total_occurrences
-        tail_start = np.searchsorted(cumulative_freq, 0.8)
-        tail_proportion = 1 - (tail_start / len(frequencies))
-        print(f"Zipf's law slope: {slope:.2f} (closer to -1 indicates closer fit to Zipf's law)")
-        print(f"R-squared value: {r_value**2:.2f}")
-        print(f"Proportion of tokens in the tail (last 20% of occurrences): {tail_proportion:.2%}")
+        tail_start = ts["top_80"]
+        ts["tail_proportion"] = 1 - (tail_start / ts["unique"])
+        print(f"Zipf's law slope: {ts['slope']:.2f} (closer to -1 indicates closer fit to Zipf's law)")
+        print(f"R-squared value: {ts['r_value'] ** 2:.2f}")
+        print(f"Proportion of tokens in the tail (last 20% of occurrences): {ts['tail_proportion']:.2%}")
         print(f"Number of tokens accounting for 80% of occurrences: {tail_start}")
+        return ts
 
     @staticmethod
     def _pyplot():

@@ -252,6 +252,17 @@ int at_any_nonfinite_f32(at_ctx* ctx, const float* v, int64_t n, int32_t* flag, 
  * processors/spec_tokenizer.py:129-147 (a Python Counter over tokens.tolist()) without leaving the device. */
 int at_token_histogram_i64(at_ctx* ctx, const int64_t* ids, int64_t n, int k, int64_t* counts, void* stream);
 
+/* Rank-frequency statistics of that histogram, still on the device (processors/spec_tokenizer.py:146-240:
+ * sorted(Counter.items()), np.cumsum / np.searchsorted, scipy.stats.linregress on the log-log curve).
+ *   sorted_counts[r], sorted_tokens[r] (DEVICE int64 / int32 [k]): the r-th most frequent token and its count
+ *     (ties in ascending token id; tokens that never occur come last with count 0);
+ *   stats (DEVICE double [8]): [0] total occurrences; [1] U = tokens that occur; [2] the number of ranks whose
+ *     cumulative share of the occurrences is below 0.8 (np.searchsorted(cumsum / total, 0.8)); [3] slope,
+ *     [4] intercept, [5] r of the least-squares line through (ln rank, ln count) over the ranks
+ *     [int(0.1 U), int(0.9 U)) (linregress' formulas, double); [6] the number of points of that fit. */
+int at_token_stats_f64(at_ctx* ctx, const int64_t* counts, int k, int64_t* sorted_counts,
+                       int32_t* sorted_tokens, double* stats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -167,3 +167,89 @@ def test_streaming_pipeline_equals_resident(be, clips, seconds, k, batch, chunk,
     assert got.tokens_train.device.type == "cpu"
     assert torch.equal(got.tokens_train, ref.tokens_train.cpu())
     assert torch.equal(got.tokens_val, ref.tokens_val.cpu())
+
+
+def test_use_convolution_through_the_stage_classes(workdir, oracle, monkeypatch, tmp_path):
+    """use_convolution=True (random-init Conv1d(1, 10, 3) along the mel axis -> d = 640) through
+    ClusterCreator -> SpecTokenizer on files, against the oracle fed the same convolved frames (d = 640 takes the
+    chunked any-d MFMA kernel)."""
+    import dataclasses
+    from audio_tokens_amd.processors import ClusterCreator, SpecTokenizer, SpectrogramGenerator
+    cfg, split, waves = workdir
+    cfg = dataclasses.replace(cfg, use_convolution=True, vocab_size=24, niter=4)
+    monkeypatch.chdir(tmp_path)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        SpectrogramGenerator(cfg).run()
+        cc = ClusterCreator(cfg)
+        cc.run()
+        st = SpecTokenizer(cfg)
+        st.run()
+    # both stages seed torch the same way before they build their Conv1d: same random kernels
+    assert torch.equal(cc.conv.weight, st.conv.weight) and torch.equal(cc.conv.bias, st.conv.bias)
+    w, b = cc.conv.weight.detach().cpu().numpy()[:, 0, :], cc.conv.bias.detach().cpu().numpy()
+
+    def convolved(frames):          # the frames the device convolution produced (feature = mel * 10 + kernel)
+        return cc.apply_convolution(frames)
+
+    train_files = sorted((Path(cfg.dest_spec_path) / "train").glob("*.npy"))
+    one = np.load(train_files[0]).T.astype(np.float32)
+    got = convolved(one)
+    assert got.shape == (one.shape[0], 640)
+    pad = np.pad(one.astype(np.float64), ((0, 0), (1, 1)))
+    ref = np.stack([sum(w[kk, j] * pad[:, j:j + 64] for j in range(3)) + b[kk] for kk in range(10)], axis=2)   # [n, mel, kernel]
+    np.testing.assert_allclose(got, ref.reshape(one.shape[0], 640), rtol=1e-4, atol=1e-4)
+    cent = None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i in range(0, len(train_files), cfg.clustering_batch_size):
+            batch = np.concatenate([np.load(f).T for f in train_files[i:i + cfg.clustering_batch_size]], 0).astype(np.float32)
+            batch = oracle.l2norm_rows(convolved(batch))
+            cent = oracle.kmeans_train(batch, cfg.vocab_size, niter=cfg.niter, init_centroids=cent).centroids
+    cent = oracle.l2norm_rows(cent)
+    got = np.load(cfg.centroids_path)
+    assert got.shape == (24, 640) and np.array_equal(bits(got), bits(cent))
+    for s in ("train", "validation"):
+        for f in sorted((Path(cfg.dest_spec_path) / s).glob("*.npy")):
+            tok = np.load(Path(cfg.dest_tokenized_path) / s / f.name)
+            ids, _ = oracle.assign(oracle.l2norm_rows(convolved(np.load(f).T.astype(np.float32))), cent)
+            assert tok.dtype == np.int64 and np.array_equal(tok, ids)
+
+
+def test_token_statistics_on_the_device_match_numpy_and_scipy(workdir, tmp_path, monkeypatch):
+    """histogram, rank-frequency order, the 80 % rank and the Zipf fit computed on the device
+    against the reference's host recipe (Counter / sorted / np.cumsum / np.searchsorted / scipy.stats.linregress)."""
+    from collections import Counter
+    from scipy import stats
+    from audio_tokens_amd.processors import SpecTokenizer
+    cfg, split, waves = workdir
+    monkeypatch.chdir(tmp_path)
+    k = 500
+    rng = np.random.default_rng(8)
+    np.save(cfg.centroids_path, rng.standard_normal((k, 64)).astype(np.float32))
+    st = SpecTokenizer(cfg)
+    zipf = 1.0 / np.arange(1, k + 1) ** 1.1
+    tokens = rng.choice(k, size=400000, p=zipf / zipf.sum()).astype(np.int64)
+    tokens = rng.permutation(k)[tokens]                        # token ids unrelated to their rank
+    ts = st.token_statistics(tokens)
+    counts = Counter(tokens.tolist())
+    ref = sorted(counts.items(), key=lambda kv: (-kv[1], kv[0]))      # ties: ascending token id
+    assert ts["total"] == len(tokens) and ts["unique"] == len(counts)
+    assert list(ts["tokens"]) == [t for t, _ in ref] and list(ts["frequencies"]) == [c for _, c in ref]
+    freq = np.array([c for _, c in ref])
+    cum = np.cumsum(freq) / freq.sum()
+    assert ts["top_80"] == int(np.searchsorted(cum, 0.8))
+    lr, lf = np.log(np.arange(1, len(freq) + 1)), np.log(freq)
+    s0, s1 = int(0.1 * len(freq)), int(0.9 * len(freq))
+    fit = stats.linregress(lr[s0:s1], lf[s0:s1])
+    assert ts["n_fit"] == s1 - s0
+    assert ts["slope"] == pytest.approx(fit.slope, rel=1e-10) and ts["intercept"] == pytest.approx(fit.intercept, rel=1e-10)
+    assert ts["r_value"] == pytest.approx(fit.rvalue, rel=1e-10)
+    # the reference's entry points (lists in, prints out) go through the same device path
+    out = st.analyze_zipf_and_tail(tuple(int(c) for c in freq))
+    assert out["slope"] == pytest.approx(fit.slope, rel=1e-10)
+    assert out["tail_proportion"] == pytest.approx(1 - np.searchsorted(cum, 0.8) / len(freq))
+    assert st.plot_token_distribution(tokens.tolist())["unique"] == len(counts)
+    assert st.analyze_tokens(tokens[:1000].tolist())["total"] == 1000
+    # and run() accumulates the histogram on the device while it tokenises
+    assert st.token_statistics()["total"] == 0
