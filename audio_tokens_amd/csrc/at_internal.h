@@ -44,6 +44,7 @@ enum at_ws_slot {
     WS_SPLIT_LIST,     // at_split_clusters_f32: the clusters that came out empty
     WS_TSTAT_IOTA,     // at_token_stats_f64: token ids before the sort, rocprim temp storage
     WS_TSTAT_TMP,
+    WS_MT_RAW,         // at_mt_cached_draws: the resident start of the mt19937(1234) stream + the state behind it
     WS_NSLOTS
 };
 
@@ -65,6 +66,9 @@ struct at_ctx {
     // cached description of what WS_LOGMEL_FB currently holds
     int fb_sr, fb_nfft, fb_nmels, fb_nw, fb_hop, fb_quads;
     const float* fb_user;
+    hipEvent_t mt_ready;   // behind the generation of WS_MT_RAW
+    int mt_have;
+    uint32_t mt_seed;
     float* fb_user_copy;   // host copy of the user filterbank the tables were built from (malloc'd; compared per call)
     int n_cus;             // multiProcessorCount of the device (read once in at_create)
     int rs_orig, rs_new;  // what WS_RESAMPLE_TAPS currently holds
@@ -93,6 +97,11 @@ struct at_ctx {
 };
 
 int at_fail(int code, const char* fmt, ...);
+// randperm.hip: resident prefix of the mt19937(seed) stream (6722 blocks of 624 outputs: covers the 4 194 304
+// swaps of the largest subsample of BASELINE.json and ~500 cluster repairs at k = 8192)
+constexpr int64_t AT_MT_CACHE_DRAWS = 624LL * 6722;
+int at_mt_cached_draws(at_ctx* ctx, uint32_t seed, hipStream_t stream, const uint32_t** raw, int64_t* raw_n,
+                       const uint32_t** state_end);
 // Returns a device buffer of at least `bytes` for `slot` (contents undefined after growth).
 void* at_ws(at_ctx* ctx, int slot, size_t bytes, hipStream_t stream);
 

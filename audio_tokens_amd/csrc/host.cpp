@@ -71,6 +71,7 @@ void at_destroy(at_ctx* ctx) {
             if (fs.ev[i]) (void)hipEventDestroy(fs.ev[i]);
     }
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    if (ctx->mt_ready) (void)hipEventDestroy(ctx->mt_ready);
     if (ctx->filter_host_misc) (void)hipHostFree(ctx->filter_host_misc);
     std::free(ctx->fb_user_copy);
     (void)hipSetDevice(prev);
@@ -112,6 +113,7 @@ void* at_ws(at_ctx* ctx, int slot, size_t bytes, hipStream_t stream) {
     ctx->ws_bytes[slot] = want;
     if (slot == WS_LOGMEL_FB) { ctx->fb_sr = ctx->fb_nfft = ctx->fb_nmels = 0; ctx->fb_user = nullptr; }
     if (slot == WS_RESAMPLE_TAPS) ctx->rs_orig = ctx->rs_new = 0;
+    if (slot == WS_MT_RAW) ctx->mt_have = 0;
     return p;
 }
 

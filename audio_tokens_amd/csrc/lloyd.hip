@@ -23,12 +23,22 @@ constexpr int WG = 256;
 // so a scan still empty-handed after 64 cycles (chance < 1e-27) has no donor to find: the kernel reports -1
 // instead of spinning (every wave reaches this exit).
 constexpr long SPLIT_CYCLES = 64;
+constexpr int SPLIT_ROUND = 4 * WG;   // candidates tested per step while the draws come from the context's cache
 
+// RandomGenerator::rand_float: mt() / float(mt.max()) -- float(2^32 - 1) is 2^32
+__device__ __forceinline__ float rand_float_of(uint32_t raw) { return __uint2float_rn(raw) * 2.3283064365386963e-10f; }
+
+// raw / raw_n: the first raw_n outputs of mt19937(1234), resident (at_mt_cached_draws); state_end: the generator's
+// 624 state words after them, from which the kernel goes on by itself if a repair ever needs more.
+// p_lds != 0: the acceptance probabilities of all k clusters live in LDS (k floats of dynamic shared memory).
 __global__ __launch_bounds__(WG) void split_clusters_kernel(int d, int k, long n, float* hassign, float* cent,
-                                                           int* __restrict__ empties, int* __restrict__ nsplit_out) {
+                                                           int* __restrict__ empties, int* __restrict__ nsplit_out,
+                                                           const uint32_t* __restrict__ raw, long raw_n,
+                                                           const uint32_t* __restrict__ state_end, int p_lds) {
+    extern __shared__ float pl[];
     __shared__ at_mt::State mt;
     __shared__ float draws[at_mt::N];
-    __shared__ int wave_val[WG / 64];
+    __shared__ int wave_val[4][WG / 64];
     __shared__ int n_empty;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
@@ -39,13 +49,13 @@ __global__ __launch_bounds__(WG) void split_clusters_kernel(int d, int k, long n
         const int c = base + t;
         const bool e = c < k && hassign[c] == 0.0f;
         const unsigned long long b = __ballot(e);
-        if (lane == 0) wave_val[wave] = __popcll(b);
+        if (lane == 0) wave_val[0][wave] = __popcll(b);
         __syncthreads();
         int off = n_empty;
-        for (int w = 0; w < wave; w++) off += wave_val[w];
+        for (int w = 0; w < wave; w++) off += wave_val[0][w];
         if (e) empties[off + __popcll(b & ((1ull << lane) - 1ull))] = c;
         __syncthreads();
-        if (t == 0) n_empty += wave_val[0] + wave_val[1] + wave_val[2] + wave_val[3];
+        if (t == 0) n_empty += wave_val[0][0] + wave_val[0][1] + wave_val[0][2] + wave_val[0][3];
         __syncthreads();
     }
     const int ne = n_empty;
@@ -54,46 +64,101 @@ __global__ __launch_bounds__(WG) void split_clusters_kernel(int d, int k, long n
         return;
     }
 
-    at_mt::seed(mt, 1234u);
-    int cur = 0, pos = at_mt::N;
     const double denom = (double)(float)(n - k);
+    auto prob = [&](int c) { return (float)(((double)hassign[c] - 1.0) / denom); };   // faiss: (hassign[cj] - 1.0) / (float)(n - k)
+    if (p_lds) {
+        for (int c = t; c < k; c += WG) pl[c] = prob(c);
+        __syncthreads();
+    }
     const double up = 1.0 + 1.0 / 1024.0, down = 1.0 - 1.0 / 1024.0;
+    long pos = 0;            // draws of the stream consumed so far
+    int cur = 0, win = 0, wlen = 0;   // slow path: `draws` holds wlen draws of which win are consumed; cur = state copy in use
+    bool own = false;
     int done = 0;
     for (int e = 0; e < ne; e++) {
         const int ci = empties[e];
         int cj0 = 0, donor = -1;
         long left = SPLIT_CYCLES * k + 1024;
-        while (left > 0) {
-            if (pos == at_mt::N) {
-                const uint32_t* nw = at_mt::regenerate(mt, cur);
-                cur ^= 1;
-                // RandomGenerator::rand_float: mt() / float(mt.max()) -- float(2^32 - 1) is 2^32
-                for (int q = t; q < at_mt::N; q += WG) draws[q] = __uint2float_rn(at_mt::temper(nw[q])) * 2.3283064365386963e-10f;
+        while (left > 0 && donor < 0) {
+            if (pos + SPLIT_ROUND <= raw_n) {
+                // four blocks of 256 candidates at once, draws straight from the resident stream
+                int firsts[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int j = i * WG + t;
+                    int cj = cj0 + j;
+                    cj -= (cj / k) * k;
+                    const float pc = p_lds ? pl[cj] : prob(cj);
+                    const bool acc = rand_float_of(raw[pos + j]) < pc;
+                    const unsigned long long b = __ballot(acc);
+                    firsts[i] = b ? i * WG + wave * 64 + (__ffsll((long long)b) - 1) : INT_MAX;
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) wave_val[i][wave] = firsts[i];
+                }
                 __syncthreads();
-                pos = 0;
+                int first = INT_MAX;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int w = 0; w < WG / 64; w++) first = min(first, wave_val[i][w]);
+                __syncthreads();
+                if (first != INT_MAX) {
+                    donor = (int)((cj0 + (long)first) % k);
+                    pos += first + 1;
+                } else {
+                    pos += SPLIT_ROUND;
+                    left -= SPLIT_ROUND;
+                    cj0 = (int)((cj0 + (long)SPLIT_ROUND) % k);
+                }
+                continue;
             }
-            const int chunk = min(at_mt::N - pos, WG);
+            // the tail of the resident stream, then the kernel's own generator: 624 draws at a time through LDS
+            if (win == wlen) {
+                if (pos < raw_n) {
+                    wlen = (int)min((long)at_mt::N, raw_n - pos);
+                    for (int q = t; q < wlen; q += WG) draws[q] = rand_float_of(raw[pos + q]);
+                } else {
+                    wlen = at_mt::N;
+                    if (!own) {
+                        for (int q = t; q < at_mt::N; q += WG) mt.st[0][q] = state_end[q];
+                        __syncthreads();
+                        own = true;
+                        cur = 0;
+                    }
+                    const uint32_t* nw = at_mt::regenerate(mt, cur);
+                    cur ^= 1;
+                    for (int q = t; q < at_mt::N; q += WG) draws[q] = rand_float_of(at_mt::temper(nw[q]));
+                }
+                __syncthreads();
+                win = 0;
+            }
+            const int chunk = min(wlen - win, WG);
             bool acc = false;
             if (t < chunk) {
                 const int cj = (cj0 + t) % k;
-                const float p = (float)(((double)hassign[cj] - 1.0) / denom);
-                acc = draws[pos + t] < p;
+                acc = draws[win + t] < (p_lds ? pl[cj] : prob(cj));
             }
             const unsigned long long b = __ballot(acc);
-            if (lane == 0) wave_val[wave] = b ? wave * 64 + (__ffsll((long long)b) - 1) : INT_MAX;
+            if (lane == 0) wave_val[0][wave] = b ? wave * 64 + (__ffsll((long long)b) - 1) : INT_MAX;
             __syncthreads();
-            const int first = min(min(wave_val[0], wave_val[1]), min(wave_val[2], wave_val[3]));
+            const int first = min(min(wave_val[0][0], wave_val[0][1]), min(wave_val[0][2], wave_val[0][3]));
             __syncthreads();
             if (first < chunk) {
                 donor = (cj0 + first) % k;
+                win += first + 1;
                 pos += first + 1;
-                break;
+            } else {
+                win += chunk;
+                pos += chunk;
+                left -= chunk;
+                cj0 = (cj0 + chunk) % k;
             }
-            pos += chunk;
-            left -= chunk;
-            cj0 = (cj0 + chunk) % k;
         }
         if (donor < 0) break;
+        // (a window opened in the slow path stays valid only while pos stays inside it: the fast path above is
+        // entered again only when a whole round fits in the resident stream, i.e. never after the tail began)
         float* dst = cent + (size_t)ci * d;
         float* src = cent + (size_t)donor * d;
         for (int j = t; j < d; j += WG) {
@@ -107,6 +172,11 @@ __global__ __launch_bounds__(WG) void split_clusters_kernel(int d, int k, long n
             hassign[donor] -= half;
         }
         done++;
+        __syncthreads();
+        if (p_lds && t == 0) {
+            pl[ci] = prob(ci);
+            pl[donor] = prob(donor);
+        }
         __syncthreads();
     }
     if (t == 0) *nsplit_out = done == ne ? ne : -1;
@@ -151,8 +221,22 @@ int at_split_clusters_f32(at_ctx* ctx, int d, int k, int64_t n, float* hassign, 
     AT_HIP(hipSetDevice(ctx->device));
     int* empties = static_cast<int*>(at_ws(ctx, WS_SPLIT_LIST, (size_t)k * sizeof(int), stream));
     if (!empties) return AT_E_NOMEM;
-    hipLaunchKernelGGL(split_clusters_kernel, dim3(1), dim3(WG), 0, stream, d, k, (long)n, hassign, centroids, empties,
-                       nsplit_out);
+    const uint32_t *raw = nullptr, *state_end = nullptr;
+    int64_t raw_n = 0;
+    int rc = at_mt_cached_draws(ctx, 1234u, stream, &raw, &raw_n, &state_end);
+    if (rc) return rc;
+    const int p_lds = k <= 16384;
+    const size_t lds = p_lds ? (size_t)k * sizeof(float) : 0;
+    if (lds > 32 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            AT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&split_clusters_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * (int)sizeof(float)));
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(split_clusters_kernel, dim3(1), dim3(WG), lds, stream, d, k, (long)n, hassign, centroids, empties,
+                       nsplit_out, raw, (long)raw_n, state_end, p_lds);
     AT_LAUNCH_CHECK();
     return AT_OK;
 }

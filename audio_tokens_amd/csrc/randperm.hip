@@ -33,7 +33,10 @@ namespace {
 using perm_radix_config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
 
 // raw[q] = the q-th output of std::mt19937(seed), q in [0, count).
-__global__ __launch_bounds__(256) void mt19937_kernel(uint32_t seed, int64_t count, uint32_t* __restrict__ raw) {
+// state_out (624 words, may be null): the generator's state after the last whole block of 624 outputs, i.e. what
+// a later kernel regenerates from to continue the stream (count must then be a multiple of 624).
+__global__ __launch_bounds__(256) void mt19937_kernel(uint32_t seed, int64_t count, uint32_t* __restrict__ raw,
+                                                      uint32_t* __restrict__ state_out) {
     __shared__ at_mt::State s;
     at_mt::seed(s, seed);
     int cur = 0;
@@ -43,6 +46,8 @@ __global__ __launch_bounds__(256) void mt19937_kernel(uint32_t seed, int64_t cou
             if (base + k < count) raw[base + k] = at_mt::temper(nw[k]);
         cur ^= 1;   // (the next regeneration writes the other copy: no barrier needed before it reads this one)
     }
+    if (state_out)
+        for (int k = threadIdx.x; k < at_mt::N; k += 256) state_out[k] = s.st[cur][k];
 }
 
 __device__ __forceinline__ uint32_t partner(const uint32_t* raw, int64_t i, int64_t n) {
@@ -94,6 +99,32 @@ __global__ void perm_resolve_kernel(const uint32_t* __restrict__ raw, const int3
 
 }  // namespace
 
+// The first AT_MT_CACHE_DRAWS outputs of mt19937(seed), computed once per context and kept: faiss seeds BOTH the
+// subsample permutation (rand_perm(n, 1234)) and every split_clusters call (RandomGenerator(1234)) with the same
+// constant, so every train() and every repair replays the same stream from its start.  *state_end = the state to
+// continue from.  Consumers on other streams are ordered behind the generation by an event.
+int at_mt_cached_draws(at_ctx* ctx, uint32_t seed, hipStream_t stream, const uint32_t** raw, int64_t* raw_n,
+                       const uint32_t** state_end) {
+    constexpr int64_t n_draws = AT_MT_CACHE_DRAWS;
+    uint32_t* buf = static_cast<uint32_t*>(at_ws(ctx, WS_MT_RAW, (size_t)(n_draws + at_mt::N) * 4, stream));
+    if (!buf) return AT_E_NOMEM;
+    if (!ctx->mt_ready) AT_HIP(hipEventCreateWithFlags(&ctx->mt_ready, hipEventDisableTiming));
+    if (!ctx->mt_have || ctx->mt_seed != seed) {
+        if (ctx->mt_have) AT_HIP(hipDeviceSynchronize());   // another seed's consumers may still be reading
+        mt19937_kernel<<<1, 256, 0, stream>>>(seed, n_draws, buf, buf + n_draws);
+        AT_LAUNCH_CHECK();
+        AT_HIP(hipEventRecord(ctx->mt_ready, stream));
+        ctx->mt_have = 1;
+        ctx->mt_seed = seed;
+    } else {
+        AT_HIP(hipStreamWaitEvent(stream, ctx->mt_ready, 0));
+    }
+    *raw = buf;
+    *raw_n = n_draws;
+    *state_end = buf + n_draws;
+    return AT_OK;
+}
+
 extern "C" int at_rand_perm_prefix_device(at_ctx* ctx, int64_t n, int64_t seed, int64_t m, int32_t* prefix, void* stream_) {
     AT_REQUIRE(ctx != nullptr, "at_rand_perm_prefix_device: ctx is null");
     AT_REQUIRE(n >= 0 && n < INT32_MAX && m >= 0 && m <= n, "at_rand_perm_prefix_device: bad sizes n=%lld m=%lld",
@@ -103,19 +134,33 @@ extern "C" int at_rand_perm_prefix_device(at_ctx* ctx, int64_t n, int64_t seed, 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int64_t steps = m < n - 1 ? m : n - 1;
     const size_t sb = (size_t)(steps > 0 ? steps : 1) * 4;
-    uint32_t* raw = static_cast<uint32_t*>(at_ws(ctx, WS_PERM_RAW, sb, stream));
+    // the draws: the context's resident mt19937(1234) stream when it is that seed and long enough, else this call's own
+    const uint32_t* raw = nullptr;
+    uint32_t* raw_own = nullptr;
+    if ((uint32_t)seed == 1234u && steps <= AT_MT_CACHE_DRAWS) {
+        int64_t have = 0;
+        const uint32_t* st_end = nullptr;
+        int rcd = at_mt_cached_draws(ctx, 1234u, stream, &raw, &have, &st_end);
+        if (rcd) return rcd;
+    } else {
+        raw_own = static_cast<uint32_t*>(at_ws(ctx, WS_PERM_RAW, sb, stream));
+        if (!raw_own) return AT_E_NOMEM;
+        raw = raw_own;
+    }
     uint32_t* ka = static_cast<uint32_t*>(at_ws(ctx, WS_PERM_KEYS_A, sb, stream));
     uint32_t* kb = static_cast<uint32_t*>(at_ws(ctx, WS_PERM_KEYS_B, sb, stream));
     uint32_t* va = static_cast<uint32_t*>(at_ws(ctx, WS_PERM_VALS_A, sb, stream));
     uint32_t* vb = static_cast<uint32_t*>(at_ws(ctx, WS_PERM_VALS_B, sb, stream));
     int32_t* prev = static_cast<int32_t*>(at_ws(ctx, WS_PERM_PREV, sb, stream));
     int32_t* last = static_cast<int32_t*>(at_ws(ctx, WS_PERM_LAST, (size_t)m * 4, stream));
-    if (!raw || !ka || !kb || !va || !vb || !prev || !last) return AT_E_NOMEM;
+    if (!ka || !kb || !va || !vb || !prev || !last) return AT_E_NOMEM;
     AT_HIP(hipMemsetAsync(last, 0xFF, (size_t)m * 4, stream));
     const unsigned tb = 256;
     if (steps > 0) {
-        mt19937_kernel<<<1, 256, 0, stream>>>((uint32_t)seed, steps, raw);
-        AT_LAUNCH_CHECK();
+        if (raw_own) {
+            mt19937_kernel<<<1, 256, 0, stream>>>((uint32_t)seed, steps, raw_own, nullptr);
+            AT_LAUNCH_CHECK();
+        }
         const unsigned gs = (unsigned)((steps + tb - 1) / tb);
         perm_keys_kernel<<<gs, tb, 0, stream>>>(raw, steps, n, ka, va);
         AT_LAUNCH_CHECK();

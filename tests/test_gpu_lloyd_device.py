@@ -62,8 +62,11 @@ def _split_case(rng, k, d, n, n_empty, big=None):
 
 @pytest.mark.parametrize("k,d,n,n_empty,big", [(64, 64, 4096, 3, None), (48, 8, 1000, 17, None), (8192, 64, 2097152, 1, None),
                                                (8192, 64, 2097152, 40, None), (500, 64, 128000, 0, None),
-                                               (1000, 128, 1003, 5, 3), (300, 640, 90000, 299, None), (16384, 128, 4194304, 7, None)])
+                                               (1000, 128, 1003, 5, 3), (300, 640, 90000, 299, None), (16384, 128, 4194304, 7, None),
+                                               (8192, 64, 2097152, 700, None), (20000, 64, 5120000, 30, None)])
 def test_split_clusters_device_equals_host(be, k, d, n, n_empty, big):
+    """(8192 clusters with 700 empty ones draw ~5.7 M numbers: past the context's resident 4.19 M-draw stream, into
+    the kernel's own generator; k = 20 000 keeps the probabilities in global memory)"""
     rng = np.random.default_rng(k + n_empty)
     h, c = _split_case(rng, k, d, n, n_empty, big)
     h_ref, c_ref = h.copy(), c.copy()
