@@ -569,7 +569,15 @@ class HipBackend(HostHelpers):
     def to_host_async(self, t: torch.Tensor):
         """-> (pinned host tensor, event): the copy is queued on the current stream, the caller's thread goes on;
         whoever needs the values waits for the event."""
-        h = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+        # pinned buffers are kept (allocating one costs milliseconds and synchronises the device): four per
+        # (shape, dtype), handed out in turn -- a reader is long done with a buffer four copies later
+        key = (tuple(t.shape), t.dtype)
+        pool = self.__dict__.setdefault("_pinned_pool", {})
+        slot = pool.get(key)
+        if slot is None:
+            slot = pool[key] = [[torch.empty(t.shape, dtype=t.dtype).pin_memory() for _ in range(4)], 0]
+        h = slot[0][slot[1] % 4]
+        slot[1] += 1
         h.copy_(t, non_blocking=True)
         return h, self.record_event()
 
