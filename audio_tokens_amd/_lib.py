@@ -18,6 +18,13 @@ AT_LAYOUT_FRAME_MAJOR = 1
 _c = ctypes
 _vp, _i32, _i64 = _c.c_void_p, _c.c_int, _c.c_int64
 
+class PrunedArgs(_c.Structure):
+    """struct at_pruned_args of include/audio_tokens_amd.h."""
+    _fields_ = [("x", _vp), ("n", _i64), ("d", _i32), ("c", _vp), ("k", _i32), ("order", _vp), ("hint_sorted", _vp),
+                ("cperm", _vp), ("ng", _i32), ("bounds", _vp), ("guess_only", _i32), ("use_filter", _i32),
+                ("prepass_done", _i32), ("image_current", _i32), ("ids", _vp), ("dist_or_null", _vp)]
+
+
 # name -> (restype, argtypes); kept in one table so tests can check every declared symbol exports
 SIGNATURES = {
     "at_version": (_i32, []),
@@ -25,6 +32,8 @@ SIGNATURES = {
     "at_create": (_i32, [_i32, _c.POINTER(_vp)]),
     "at_destroy": (None, [_vp]),
     "at_workspace_bytes": (_i64, [_vp]),
+    "at_debug_set": (_i32, [_vp, _c.c_char_p, _i32]),
+    "at_debug_get": (_i32, [_vp, _c.c_char_p, _c.POINTER(_i32)]),
     "at_rand_perm_mt19937": (_i32, [_i64, _i64, _vp]),
     "at_rand_perm_prefix_mt19937": (_i32, [_i64, _i64, _i64, _vp]),
     "at_rand_perm_prefix_device": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp]),
@@ -49,7 +58,7 @@ SIGNATURES = {
                                    _c.POINTER(_i64), _vp]),
     "at_group_means_f32": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "at_group_neighbours_f32": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
-    "at_assign_pruned_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "at_assign_pruned_f32": (_i32, [_vp, _vp, _vp]),   # (ctx, const at_pruned_args*, stream)
     "at_prune_mask_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp]),
     "at_gather_rows_f32": (_i32, [_vp, _vp, _i32, _vp, _i64, _vp, _vp]),
     "at_centroid_accum_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),

@@ -124,6 +124,18 @@ class HipBackend(HostHelpers):
         self.device = device
         self.ctx = _lib.context(device.index)
         self.assign_trace = None  # set to a list to collect (kind, n, d, k, start_event, end_event)
+        # host-side A/B switches, read from the environment once (the native ones: at_debug.h, self.debug_set)
+        self.switches = {"filter": os.environ.get("AT_FILTER", "1") != "0",
+                         "c2f_fused": os.environ.get("AT_C2F_FUSED", "1") != "0"}
+
+    # -- development switches (include/at_debug.h) ------------------------------------------
+    def debug_set(self, name: str, value: int) -> None:
+        _lib.check(self.lib.at_debug_set(self.ctx.handle, name.encode(), int(value)))
+
+    def debug_get(self, name: str) -> int:
+        v = ctypes.c_int(0)
+        _lib.check(self.lib.at_debug_get(self.ctx.handle, name.encode(), ctypes.byref(v)))
+        return int(v.value)
 
     # -- plumbing --------------------------------------------------------------------------
     def _stream(self) -> _vp:
@@ -371,7 +383,7 @@ class HipBackend(HostHelpers):
         fp16 filter sweep over all groups of means instead of the dense fp32 sweep."""
         n, d = x.shape
         ngm = means.shape[0]
-        if d not in (64, 128) or n < 20 or os.environ.get("AT_FILTER", "1") == "0":
+        if d not in (64, 128) or n < 20 or not self.switches["filter"]:
             return self.assign(x, means, want_dist=False)[0]
         key = (n, ngm)
         if getattr(self, "_ident", (None,))[0] != key:
@@ -407,8 +419,7 @@ class HipBackend(HostHelpers):
         means = self.group_means(c, cperm)
         if gnbr is None:
             gnbr = self.group_neighbours(means)
-        if (coherent and x.shape[1] in (64, 128) and os.environ.get("AT_FILTER", "1") != "0"
-                and os.environ.get("AT_C2F_FUSED", "1") != "0"):
+        if coherent and x.shape[1] in (64, 128) and self.switches["filter"] and self.switches["c2f_fused"]:
             guess, gdis = self.assign_coarse(x, c, cperm, means, gnbr)
             return self.assign_pruned(x, c, self.visit_order(guess, gdis, c.shape[0]), cperm, dmin, want_dist=want_dist)
         gx = self._nearest_mean(x, means)
@@ -425,7 +436,7 @@ class HipBackend(HostHelpers):
         x, c = self._f32(x), self._f32(c)
         n, d = x.shape
         if filter is None:
-            filter = os.environ.get("AT_FILTER", "1") != "0"
+            filter = self.switches["filter"]
         use_filter = bool(filter) and d in (64, 128)
         k = c.shape[0]
         order, hint_sorted = order
@@ -434,7 +445,7 @@ class HipBackend(HostHelpers):
         dist = self.empty((n,), torch.float32) if want_dist else None
         rec = self.assign_trace
         # exact filtered calls do their pre-pass (guess distances + group masks) inside the sweep kernel
-        fused = use_filter and mode == 0 and os.environ.get("AT_FILTER_FUSED", "1") != "0"
+        fused = use_filter and mode == 0 and self.debug_get("filter_fused") != 0
         with torch.cuda.device(self.device):
             if not fused:  # pre-pass first, so that the events below bracket the sweep kernel only
                 _lib.check(self.lib.at_prune_mask_f32(self.ctx.handle, _ptr(x), n, d, _ptr(c), k, _ptr(order),
@@ -442,11 +453,13 @@ class HipBackend(HostHelpers):
             if rec is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(torch.cuda.current_stream(self.device))
-            _lib.check(self.lib.at_assign_pruned_f32(self.ctx.handle, _ptr(x), n, d, _ptr(c), k, _ptr(order),
-                                                     _ptr(hint_sorted), _ptr(cperm), ng, _ptr(dmin),
-                                                     mode | (2 if use_filter else 0),
-                                                     (0 if fused else 1) | (2 if image_current else 0), _ptr(ids),
-                                                     _ptr(dist), self._stream()))
+            args = _lib.PrunedArgs(x=x.data_ptr(), n=n, d=d, c=c.data_ptr(), k=k, order=order.data_ptr(),
+                                   hint_sorted=hint_sorted.data_ptr(), cperm=cperm.data_ptr(), ng=ng,
+                                   bounds=dmin.data_ptr() if dmin is not None else None, guess_only=1 if mode else 0,
+                                   use_filter=1 if use_filter else 0, prepass_done=0 if fused else 1,
+                                   image_current=1 if image_current else 0, ids=ids.data_ptr(),
+                                   dist_or_null=dist.data_ptr() if dist is not None else None)
+            _lib.check(self.lib.at_assign_pruned_f32(self.ctx.handle, ctypes.byref(args), self._stream()))
         if rec is not None:
             e1.record(torch.cuda.current_stream(self.device))
             rec.append(("pruned" if mode == 0 else "coarse", n, d, k, e0, e1))

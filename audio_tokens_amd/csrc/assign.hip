@@ -1115,11 +1115,6 @@ int launch_mfma(at_ctx* ctx, const float* x, int64_t n, const float* c, int k, i
     return AT_OK;
 }
 
-// Development switch (A/B of kernel shapes on the GPU box): AT_ASSIGN_VARIANT, default 0.
-int assign_variant() {
-    const char* e = std::getenv("AT_ASSIGN_VARIANT");
-    return e ? std::atoi(e) : 0;
-}
 
 }  // namespace
 
@@ -1144,7 +1139,7 @@ extern "C" int at_assign_f32(at_ctx* ctx, const float* x, int64_t n, int d, cons
         AT_REQUIRE(at_aligned16(x), "at_assign_f32: x must be 16-byte aligned");
         // Shipped shapes: LDS-DMA staging, 128-centroid tiles at d=64 (64 at d=128), 2 waves/SIMD.
         // AT_ASSIGN_VARIANT=1 selects the register-staged 64-centroid-tile kernel (A/B aid).
-        const int v = assign_variant();
+        const int v = ctx->dbg.assign_variant;
         if (d == 64) {
             if (v == 1) return launch_mfma<64, 2, 2, false, 2>(ctx, x, n, c, k, ids, dist, stream);
             if (v == 3) return launch_mfma<64, 2, 4, true, 2, true>(ctx, x, n, c, k, ids, dist, stream);
@@ -1155,7 +1150,7 @@ extern "C" int at_assign_f32(at_ctx* ctx, const float* x, int64_t n, int d, cons
         return launch_mfma<128, 1, 2, true, 2>(ctx, x, n, c, k, ids, dist, stream);
     }
 
-    if (d % 4 == 0 && at_aligned16(x) && assign_variant() != 2) {
+    if (d % 4 == 0 && at_aligned16(x) && ctx->dbg.assign_variant != 2) {
         constexpr int NB = 2, NA = 2;
         const int nchunks = (d + DC - 1) / DC;
         const int ntiles = (k + tile_rows(NA) - 1) / tile_rows(NA);
@@ -1267,8 +1262,7 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
         if (rc) return rc;
     }
     // exact filtered calls without a pre-pass done by the caller: the sweep does it in its prologue
-    const char* fz = std::getenv("AT_FILTER_FUSED");  // A/B aid: 0 = separate pre-pass kernel
-    const bool fuse = filter && mode == 0 && !prepass_done && !(fz && std::atoi(fz) == 0);
+    const bool fuse = filter && mode == 0 && !prepass_done && ctx->dbg.filter_fused != 0;   // (switch: 0 = separate pre-pass kernel)
     if (!prepass_done && !fuse) {
         int rc = at_prune_prepass(ctx, x, n, D, c, k, order, hint_sorted, dmin, ng, bd, mask, ngw, mode, stream);
         if (rc) return rc;
@@ -1285,8 +1279,7 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
         // statistics (and the list-length verdicts) of earlier calls whose words have arrived: polled, not waited for
         int rcp = at_filter_resolve_pending(ctx, false);
         if (rcp) return rcp;
-        const char* sy = std::getenv("AT_FILTER_SYNC");  // A/B aid: 1 = always the synchronous form
-        const bool async_form = mode == 0 && !ctx->filter_force_sync && !(sy && std::atoi(sy) == 1);
+        const bool async_form = mode == 0 && !ctx->filter_force_sync && ctx->dbg.filter_sync != 1;
         int slot = AT_FILTER_RING;
         if (async_form) {
             if (ctx->fring_count == AT_FILTER_RING) {   // the host is a whole ring ahead of the device: wait for the oldest
@@ -1371,8 +1364,7 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
         if (rc) return rc;
     }
     // d = 64: register-staged A operand (no LDS); AT_PRUNE_KERNEL=0 selects the LDS-DMA form (A/B aid)
-    const char* ev = std::getenv("AT_PRUNE_KERNEL");
-    if (!(ev && std::atoi(ev) == 0) && D == 64 && NB <= 2)
+    if (ctx->dbg.prune_kernel != 0 && D == 64 && NB <= 2)
         hipLaunchKernelGGL((assign_mfma_pruned_reg_kernel<D, NB>), dim3((unsigned)((n2 + rows_per_wg - 1) / rows_per_wg)),
                            dim3(64), 0, stream, x, (long)n2, img, ng, order2, hint2, bd, mask, ngw,
                            reinterpret_cast<long*>(ids), dist);
@@ -1384,27 +1376,30 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
     return AT_OK;
 }
 
-extern "C" int at_assign_pruned_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
-                                    const uint32_t* order, const uint32_t* hint_sorted, const int32_t* cperm,
-                                    int ng, const float* dmin, int mode, int prepass_done, int64_t* ids,
-                                    float* dist, void* stream_) {
+extern "C" int at_assign_pruned_f32(at_ctx* ctx, const at_pruned_args* a, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    AT_REQUIRE(ctx, "at_assign_pruned_f32: ctx is null");
-    AT_REQUIRE(x && c && order && hint_sorted && cperm && (dmin || (mode & 1)) && ids, "at_assign_pruned_f32: null pointer");
-    AT_REQUIRE(mode >= 0 && mode <= 3, "at_assign_pruned_f32: mode must be 0..3");
-    const bool filter = (mode & 2) != 0;
-    mode &= 1;
+    AT_REQUIRE(ctx && a, "at_assign_pruned_f32: ctx / args is null");
+    const float *x = a->x, *c = a->c, *dmin = a->bounds;
+    const int64_t n = a->n;
+    const int d = a->d, k = a->k, ng = a->ng;
+    const uint32_t *order = a->order, *hint_sorted = a->hint_sorted;
+    const int32_t* cperm = a->cperm;
+    int64_t* ids = a->ids;
+    float* dist = a->dist_or_null;
+    const int mode = a->guess_only ? 1 : 0;
+    const bool filter = a->use_filter != 0;
+    const int prepass_done = a->prepass_done ? 1 : 0;
+    AT_REQUIRE(x && c && order && hint_sorted && cperm && (dmin || mode == 1) && ids, "at_assign_pruned_f32: null pointer");
     AT_REQUIRE(d == 64 || d == 128, "at_assign_pruned_f32: d must be 64 or 128");
     AT_REQUIRE(n >= 20 && n < (int64_t)UINT32_MAX && k > 0 && ng > 0 && ng <= 512 && ng * 32 >= k,
                "at_assign_pruned_f32: bad sizes n=%lld k=%d ng=%d", (long long)n, k, ng);
     AT_REQUIRE(at_aligned16(x) && at_aligned16(c), "at_assign_pruned_f32: x and c must be 16-byte aligned");
     AT_HIP(hipSetDevice(ctx->device));
-    ctx->img16_trusted = (prepass_done & 2) != 0;  // consumed (and cleared) by the filter sweep
-    prepass_done &= 1;
+    ctx->img16_trusted = a->image_current != 0;  // consumed (and cleared) by the filter sweep
     if (d == 64) {
-        const char* e = std::getenv("AT_PRUNE_NB");
-        if (e && std::atoi(e) == 4) return launch_pruned<64, 4>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, prepass_done != 0, filter, ids, dist, stream);
-        if (e && std::atoi(e) == 1) return launch_pruned<64, 1>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, prepass_done != 0, filter, ids, dist, stream);
+        const int nbsw = ctx->dbg.prune_nb;
+        if (nbsw == 4) return launch_pruned<64, 4>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, prepass_done != 0, filter, ids, dist, stream);
+        if (nbsw == 1) return launch_pruned<64, 1>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, prepass_done != 0, filter, ids, dist, stream);
         return launch_pruned<64, 2>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, prepass_done != 0, filter, ids, dist, stream);
     }
     return launch_pruned<128, 2>(ctx, x, n, c, k, order, hint_sorted, cperm, ng, dmin, mode, prepass_done != 0, filter, ids, dist, stream);

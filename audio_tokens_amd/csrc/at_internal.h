@@ -7,6 +7,7 @@
 #include <cstdio>
 
 #include "../../include/audio_tokens_amd.h"
+#include "../../include/at_debug.h"
 
 // Workspace slots of a context (grown on demand, never shrunk).
 enum at_ws_slot {
@@ -59,8 +60,25 @@ struct at_filter_slot {
     int64_t rows;
 };
 
+// Development switches (include/at_debug.h).  Read from the environment ONCE, in at_create -- never on a call
+// path -- and changed afterwards only through at_debug_set.  Every one selects another route to the same bits
+// (tests/test_gpu_ops.py::test_ab_switches_leave_the_bits_alone).
+struct at_debug {
+    int assign_variant;   // AT_ASSIGN_VARIANT   shape of the dense fp32 sweep (0 = default)
+    int filter_fused;     // AT_FILTER_FUSED     1 = pre-pass inside the filter sweep (default), 0 = separate kernel
+    int filter_sync;      // AT_FILTER_SYNC      1 = exact calls always take the synchronous form
+    int prune_kernel;     // AT_PRUNE_KERNEL     0 = LDS-DMA form of the d = 64 fp32 pruned sweep
+    int prune_nb;         // AT_PRUNE_NB         row tiles per wave of the fp32 pruned sweep (1, 2, 4; 0 = default)
+    int filter_screen;    // AT_FILTER_SCREEN    0 = always evaluate all three fp16 products
+    int filter_nb;        // AT_FILTER_NB        row tiles per wave of the filter sweep (2, 4; 0 = by size)
+    int filter_wps2;      // AT_FILTER_WPS2      1 = two waves per SIMD in the Lloyd-sized filter sweeps
+    int dmin_kernel;      // AT_DMIN_KERNEL      0 = fp32 vector-ALU kernel for the centroid-to-group bounds
+    int resample_simple;  // AT_RESAMPLE_SIMPLE  1 = one-thread-per-sample resampler
+};
+
 struct at_ctx {
     int device;
+    at_debug dbg;
     void* ws[WS_NSLOTS];
     size_t ws_bytes[WS_NSLOTS];
     // cached description of what WS_LOGMEL_FB currently holds

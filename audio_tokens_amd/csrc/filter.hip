@@ -1074,15 +1074,14 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
     float ta = 0.0f, tb = 0.0f, ra = 0.0f, rb = 0.0f;
     filter_tau(d, &ta, &tb);
     filter_rho(d, &ra, &rb);
-    const char* sc = std::getenv("AT_FILTER_SCREEN");  // A/B aid: 0 = always evaluate all three products
-    const int screen = (sc && std::atoi(sc) == 0) ? 0 : 1;
+    const int screen = ctx->dbg.filter_screen != 0;   // (switch: 0 = always evaluate all three products)
     // Rows per wave = 32 * NB.  Lloyd-sized exact sweeps (rows sorted by guess, <= 8 M of them) run two
     // tiles per wave at three waves per SIMD (168 registers, no second fragment set: occupancy hides the
     // loads; 3 % faster than four tiles at two waves); the long tokenise sweeps and the guess generators
     // keep four tiles per wave.  AT_FILTER_NB=2|4 forces the choice (A/B aid).
-    const char* nbv = std::getenv("AT_FILTER_NB");
-    const bool wps3 = fused && d == 64 && (nbv ? std::atoi(nbv) == 2 : n <= (int64_t)8 << 20) && !std::getenv("AT_FILTER_WPS2");
-    const int NB = (wps3 || (nbv && std::atoi(nbv) == 2)) ? 2 : 4;
+    const int nbv = ctx->dbg.filter_nb;
+    const bool wps3 = fused && d == 64 && (nbv ? nbv == 2 : n <= (int64_t)8 << 20) && !ctx->dbg.filter_wps2;
+    const int NB = (wps3 || nbv == 2) ? 2 : 4;
     const dim3 grid((unsigned)((n + 32 * NB - 1) / (32 * NB)));
     AT_REQUIRE(d == 64 || d == 128, "at_filter_sweep: d must be 64 or 128");
     if (collect) {  // exact calls synchronise anyway: time the kernel for at_filter_stats

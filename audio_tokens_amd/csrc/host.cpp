@@ -28,9 +28,45 @@ int at_fail(int code, const char* fmt, ...) {
     return code;
 }
 
+namespace {
+struct DebugField { const char* name; const char* env; int at_debug::*field; int def; };
+const DebugField kDebugFields[] = {
+    {"assign_variant", "AT_ASSIGN_VARIANT", &at_debug::assign_variant, 0},
+    {"filter_fused", "AT_FILTER_FUSED", &at_debug::filter_fused, 1},
+    {"filter_sync", "AT_FILTER_SYNC", &at_debug::filter_sync, 0},
+    {"prune_kernel", "AT_PRUNE_KERNEL", &at_debug::prune_kernel, 1},
+    {"prune_nb", "AT_PRUNE_NB", &at_debug::prune_nb, 0},
+    {"filter_screen", "AT_FILTER_SCREEN", &at_debug::filter_screen, 1},
+    {"filter_nb", "AT_FILTER_NB", &at_debug::filter_nb, 0},
+    {"filter_wps2", "AT_FILTER_WPS2", &at_debug::filter_wps2, 0},
+    {"dmin_kernel", "AT_DMIN_KERNEL", &at_debug::dmin_kernel, 1},
+    {"resample_simple", "AT_RESAMPLE_SIMPLE", &at_debug::resample_simple, 0},
+};
+}  // namespace
+
 extern "C" {
 
 int at_version(void) { return AT_VERSION; }
+
+int at_debug_set(at_ctx* ctx, const char* name, int value) {
+    AT_REQUIRE(ctx && name, "at_debug_set: null argument");
+    for (const DebugField& f : kDebugFields)
+        if (std::strcmp(f.name, name) == 0) {
+            ctx->dbg.*(f.field) = value;
+            return AT_OK;
+        }
+    return at_fail(AT_E_INVALID, "at_debug_set: no switch named '%s'", name);
+}
+
+int at_debug_get(const at_ctx* ctx, const char* name, int* value) {
+    AT_REQUIRE(ctx && name && value, "at_debug_get: null argument");
+    for (const DebugField& f : kDebugFields)
+        if (std::strcmp(f.name, name) == 0) {
+            *value = ctx->dbg.*(f.field);
+            return AT_OK;
+        }
+    return at_fail(AT_E_INVALID, "at_debug_get: no switch named '%s'", name);
+}
 
 const char* at_last_error(void) { return g_last_error.c_str(); }
 
@@ -50,6 +86,10 @@ int at_create(int device, at_ctx** out) {
     std::memset(c, 0, sizeof *c);
     c->device = device;
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    for (const DebugField& f : kDebugFields) {   // the only place the environment is read
+        const char* e = std::getenv(f.env);
+        c->dbg.*(f.field) = e ? std::atoi(e) : f.def;
+    }
     *out = c;
     return AT_OK;
 }

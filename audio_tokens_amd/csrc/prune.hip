@@ -352,8 +352,8 @@ int at_group_min_dist_f32(at_ctx* ctx, const float* c, int k, int d, const int32
     AT_REQUIRE(ctx && c && cperm && dmin && k > 0 && d > 0 && ng > 0, "at_group_min_dist_f32: bad arguments");
     AT_REQUIRE((d == 64 || d == 128) && at_aligned16(c), "at_group_min_dist_f32: d must be 64 or 128");
     AT_HIP(hipSetDevice(ctx->device));
-    const char* dv = std::getenv("AT_DMIN_KERNEL");  // A/B aid: 0 = the fp32 vector-ALU kernel below
-    if (!(dv && std::atoi(dv) == 0)) return at_group_min_dist_f16(ctx, c, k, d, cperm, ng, dmin, stream);
+    if (ctx->dbg.dmin_kernel != 0) return   // (switch: 0 = the fp32 vector-ALU kernel below)
+        at_group_min_dist_f16(ctx, c, k, d, cperm, ng, dmin, stream);
     ctx->img16_c = nullptr;  // (no fp16 image is left behind by this form)
     const dim3 grid(ng, (k + WG - 1) / WG);
     if (d == 64)

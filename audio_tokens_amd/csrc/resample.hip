@@ -171,7 +171,7 @@ int at_resample_f32(at_ctx* ctx, const float* wave, int64_t n_clips, int64_t L, 
     const float* taps = static_cast<const float*>(ctx->ws[WS_RESAMPLE_TAPS]);
     constexpr int RI = 4;
     constexpr int kSegFloats = 8192;  // 32 KiB of LDS per workgroup
-    const bool force_simple = std::getenv("AT_RESAMPLE_SIMPLE") != nullptr;  // test switch
+    const bool force_simple = ctx->dbg.resample_simple != 0;  // test switch
     const long fit = ((long)kSegFloats - K) / orig + 1;  // i-steps whose input span fits the segment
     if (fit >= RI && !force_simple) {
         const long n_i = (out_len + nw - 1) / nw;

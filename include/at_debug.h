@@ -1,0 +1,41 @@
+/*
+ * at_debug.h -- development and test hooks of libaudio_tokens_amd.so.  NOT part of the operator surface
+ * (include/audio_tokens_amd.h): nothing a binding of the reference's operators needs is declared here.
+ *
+ *   at_debug_set / at_debug_get   A/B switches of a context.  Each selects another route to the SAME bits
+ *                                 (another kernel shape, a separate pre-pass, the synchronous form ...).  They are
+ *                                 initialised from the AT_* environment variables once, in at_create, and never read
+ *                                 from the environment again; names:
+ *                                   assign_variant filter_fused filter_sync prune_kernel prune_nb filter_screen
+ *                                   filter_nb filter_wps2 dmin_kernel resample_simple
+ *   at_prune_stats                running totals over the context's exact pruned sweeps: 32x32 accumulators computed /
+ *                                 accumulators of the dense sweep.  Synchronises the device; reset != 0 clears them.
+ *   at_filter_stats               fp16-split filter: rows swept / rows handed to the fp32 redo, the summed HIP-event
+ *                                 time of the stage-1 kernel over `sweeps` exact calls, 32x32 tiles multiplied hi*hi /
+ *                                 refined with the lo products (NULL skips a field).  Waits for the calls in flight.
+ *   at_filter_probe_f32           stage 1 of an exact call only: approx[2i], approx[2i+1] = approximate |c|^2 - 2 x.c
+ *                                 of row i's winner and its gap to the runner-up; *listed = rows it would hand on.
+ */
+#ifndef AUDIO_TOKENS_AMD_DEBUG_H
+#define AUDIO_TOKENS_AMD_DEBUG_H
+
+#include "audio_tokens_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int at_debug_set(at_ctx* ctx, const char* name, int value);
+int at_debug_get(const at_ctx* ctx, const char* name, int* value);
+
+int at_prune_stats(at_ctx* ctx, int64_t* needed_host, int64_t* total_host, int reset);
+int at_filter_stats(at_ctx* ctx, int64_t* rows, int64_t* listed, double* sweep_ms, int64_t* sweeps,
+                    int64_t* tiles, int64_t* refined, int reset);
+int at_filter_probe_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
+                        const uint32_t* order, const uint32_t* hint_sorted, const int32_t* cperm, int ng,
+                        const float* dmin, int64_t* ids, float* approx, int64_t* listed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUDIO_TOKENS_AMD_DEBUG_H */

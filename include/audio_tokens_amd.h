@@ -139,18 +139,21 @@ int at_assign_hinted_f32(at_ctx* ctx, const float* x, int64_t n, int d, const fl
  * at_group_means_f32: means[g] (DEVICE float [ng][d]) = mean row of group g.
  * at_group_neighbours_f32: gnbr[g] (DEVICE uint32 [ng][ceil(ng/32)]) = bit set of the nnb groups whose
  *   means are nearest to mean g, g itself included (ng <= 512, d <= 128); input of the guess generators.
- * at_assign_pruned_f32, mode 0: the answer of at_assign_f32, bit for bit (d = 64 or 128, n >= 20,
- *   ng <= 512).  Every row's guess hint_sorted[p] (for row order[p]) is scored exactly first; a
- *   32-centroid group is then skipped for a 32-row tile when the triangle inequality, with a margin
+ * at_assign_pruned_f32 (arguments: struct at_pruned_args below).  guess_only = 0: the answer of at_assign_f32, bit
+ *   for bit (d = 64 or 128, n >= 20, ng <= 512).  Every row's guess hint_sorted[p] (for row order[p]) is scored
+ *   exactly first; a 32-centroid group is then skipped for a 32-row tile when the triangle inequality, with a margin
  *   that covers the fp32 rounding of the distances, rules it out for all of the tile's rows.
- *   mode 1 (a guess generator, NOT exact): hint_sorted holds a GROUP id per row; each row gets the
- *   best centroid among the groups named by its 32-row tile; dmin_or_null is then read as an
- *   optional uint32 [ng][ceil(ng/32)] table: bit set = group worth searching for a row naming g.  The unguided exact search is
- *   nearest group mean -> mode 1 -> mode 0 with the mode-1 answers as guesses. */
+ *   guess_only = 1 (a guess generator, NOT exact): hint_sorted holds a GROUP id per row; each row gets the best
+ *   centroid among the groups named by its 32-row tile; `bounds` is then read as an optional uint32
+ *   [ng][ceil(ng/32)] table: bit set = group worth searching for a row naming g.  The unguided exact search is
+ *   nearest group mean -> guess_only = 1 -> guess_only = 0 with those answers as guesses.
+ *   use_filter != 0: stage 1 is the fp16-split filter (csrc/filter.hip: three fp16 MFMAs per fp32 one, a winner
+ *   accepted only when the runner-up is provably out of reach of the fp32 contract), the remaining rows are redone in
+ *   fp32: ids/dist are bit-identical to use_filter = 0, and the call needs no host round trip (the redo kernel reads
+ *   the list length on the device) unless earlier calls on this context listed more than n/16 rows.
+ *   image_current != 0: the caller vouches that the fp16 image at_group_min_dist_f32 built is still current (same c,
+ *   cperm; centroids unchanged since), so it is reused. */
 int at_group_rows_kd_host(const float* rows_host, int k, int d, int leaf, int32_t* perm_out_host);
-/* Running totals over the context's mode-0 pruned sweeps: 32x32 accumulators actually computed and
- * accumulators a dense sweep would compute.  Synchronises the device; reset != 0 clears them. */
-int at_prune_stats(at_ctx* ctx, int64_t* needed_host, int64_t* total_host, int reset);
 int at_group_min_dist_f32(at_ctx* ctx, const float* c, int k, int d, const int32_t* cperm, int ng,
                           float* dmin, void* stream);
 int at_visit_order_f32(at_ctx* ctx, const int64_t* ids, const float* dis_or_null, int64_t n, int k,
@@ -159,10 +162,25 @@ int at_group_means_f32(at_ctx* ctx, const float* c, int k, int d, const int32_t*
                        float* means, void* stream);
 int at_group_neighbours_f32(at_ctx* ctx, const float* means, int ng, int d, int nnb, uint32_t* gnbr,
                             void* stream);
-int at_assign_pruned_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
-                         const uint32_t* order, const uint32_t* hint_sorted, const int32_t* cperm,
-                         int ng, const float* dmin_or_null, int mode, int prepass_done, int64_t* ids,
-                         float* dist_or_null, void* stream);
+typedef struct at_pruned_args {
+    const float* x;              /* DEVICE [n][d] rows */
+    int64_t n;
+    int d;
+    const float* c;              /* DEVICE [k][d] centroids */
+    int k;
+    const uint32_t* order;       /* DEVICE [n]: rows in visiting order (at_visit_order_f32) */
+    const uint32_t* hint_sorted; /* DEVICE [n]: the guess of row order[p] (guess_only: its group) */
+    const int32_t* cperm;        /* DEVICE [ng*32]: spatial grouping (at_group_rows_kd_host), -1 padded */
+    int ng;
+    const float* bounds;         /* DEVICE: dmin [k][ng] (at_group_min_dist_f32); guess_only: optional bit table */
+    int guess_only;              /* 0 = exact search, 1 = guess generator */
+    int use_filter;              /* 0 = fp32 pruned sweep, 1 = fp16-split filter first (same bits) */
+    int prepass_done;            /* 1 = at_prune_mask_f32 ran just before with the same arguments */
+    int image_current;           /* 1 = the fp16 image of (c, cperm) left by at_group_min_dist_f32 is still valid */
+    int64_t* ids;                /* DEVICE [n] out */
+    float* dist_or_null;         /* DEVICE [n] out */
+} at_pruned_args;
+int at_assign_pruned_f32(at_ctx* ctx, const at_pruned_args* args, void* stream);
 /* The pre-pass of at_assign_pruned_f32 alone (per-row bound and per-tile group masks into the
  * context's workspace).  at_assign_pruned_f32 runs it itself unless prepass_done != 0, in which case
  * it must directly follow this call with the same arguments on the same stream. */
@@ -170,16 +188,7 @@ int at_prune_mask_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float
                       const uint32_t* order, const uint32_t* hint_sorted, int ng,
                       const float* dmin_or_null, int mode, void* stream);
 
-/* The exact sweeps above accept mode | 2: stage 1 is then the fp16-split filter
- * (csrc/filter.hip: three fp16 MFMAs per fp32 one, winner accepted only when the runner-up is
- * provably out of reach of the fp32 contract), the remaining rows are redone by the fp32 sweep, so
- * ids/dist are bit-identical to mode without the flag, and the call is asynchronous (the redo kernel reads the
- * list length on the device) unless a previous call on this context listed more than n/16 rows.  prepass_done | 2 tells the call that the fp16 image
- * at_group_min_dist_f32 built is still current (same c, cperm; centroids unchanged since), so it is reused.  at_filter_stats reports rows swept / redone
- * the summed HIP-event time of the stage-1 kernel over `sweeps` exact calls, and how many 32x32
- * tiles it multiplied (hi*hi: d/16 MFMAs) / refined (2 d/16 more) (NULL to skip any of them);
- * at_filter_probe_f32 is a test hook (stage 1 only; approx[2i], approx[2i+1] = approximate
- * |c|^2 - 2 x.c of the winner and its gap to the runner-up). */
+/* (Counters of the pruned / filtered sweeps and the stage-1 test hook live in at_debug.h.) */
 /* Guess generator for rows in their own (coherent) order -- consecutive frames of clips, i.e. tokenise:
  * nearest of the ng group means (means [ng, d], at_group_means_f32) -> the groups the neighbour table
  * gnbr [ng][ceil(ng/32)] names -> best centroid among them, one launch, rows read once.  ids are guesses
@@ -188,11 +197,6 @@ int at_assign_coarse_f32(at_ctx* ctx, const float* x, int64_t n, int d, const fl
                          const int32_t* cperm, int ng, const float* means, const uint32_t* gnbr,
                          int64_t* ids, float* dist, void* stream);
 
-int at_filter_stats(at_ctx* ctx, int64_t* rows, int64_t* listed, double* sweep_ms, int64_t* sweeps,
-                    int64_t* tiles, int64_t* refined, int reset);
-int at_filter_probe_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
-                        const uint32_t* order, const uint32_t* hint_sorted, const int32_t* cperm, int ng,
-                        const float* dmin, int64_t* ids, float* approx, int64_t* listed, void* stream);
 
 /* The same m entries as at_rand_perm_prefix_mt19937(n, seed, m, .), bit for bit, computed on the device
  * (csrc/randperm.hip: the mt19937 stream by one workgroup, then the Fisher-Yates prefix resolved with a

@@ -44,3 +44,25 @@ def be():
     """The product backend (HIP only).  GPU tests call through the C ABI with it."""
     from audio_tokens_amd.backend import default_backend
     return default_backend()
+
+
+_NATIVE_DEFAULTS = {"assign_variant": 0, "filter_fused": 1, "filter_sync": 0, "prune_kernel": 1, "prune_nb": 0,
+                    "filter_screen": 1, "filter_nb": 0, "filter_wps2": 0, "dmin_kernel": 1, "resample_simple": 0}
+
+
+@pytest.fixture()
+def switches(be):
+    """Sets A/B switches for one test -- native ones through at_debug_set, host-side ones in be.switches -- and puts
+    the defaults back afterwards.  (The library reads the AT_* environment only once, in at_create.)"""
+    host_before = dict(be.switches)
+
+    def set_(**kw):
+        for name, value in kw.items():
+            if name in be.switches:
+                be.switches[name] = bool(value)
+            else:
+                be.debug_set(name, value)
+    yield set_
+    be.switches.update(host_before)
+    for name, value in _NATIVE_DEFAULTS.items():
+        be.debug_set(name, value)

@@ -86,7 +86,7 @@ def test_config1_two_batches_against_the_oracle(be, oracle):
 
 
 @pytest.mark.parametrize("k,n1,n2", [(2048, 60000, 40000), (8192, 70000, 30000)])
-def test_kmeans_d128_pruned_path_matches_oracle(be, oracle, monkeypatch, k, n1, n2):
+def test_kmeans_d128_pruned_path_matches_oracle(be, oracle, switches, k, n1, n2):
     """configs[2] / configs[4] feature width: assign_f16filter_kernel<128,...>, its fused pre-pass and the d=128
     redo paths inside a full train(), cold start then warm start, filter on and off, against the oracle."""
     from audio_tokens_amd.ops import Kmeans
@@ -100,12 +100,10 @@ def test_kmeans_d128_pruned_path_matches_oracle(be, oracle, monkeypatch, k, n1, 
         warnings.simplefilter("ignore")
         r1 = oracle.kmeans_train(x[:n1], k, niter=niter)
         r2 = oracle.kmeans_train(x[n1:], k, niter=niter, init_centroids=r1.centroids)
-        for label, env in (("filtered", {}), ("fp32 pruned", {"AT_FILTER": "0"}), ("dense", None)):
-            monkeypatch.delenv("AT_FILTER", raising=False)
-            for key, val in (env or {}).items():
-                monkeypatch.setenv(key, val)
+        for label, use_filter, prune in (("filtered", True, True), ("fp32 pruned", False, True), ("dense", True, False)):
+            switches(filter=use_filter)
             km = Kmeans(128, k, niter=niter, backend=be)
-            km.prune = env is not None
+            km.prune = prune
             km.train(x[:n1])
             assert np.array_equal(bits(km.centroids), bits(r1.centroids)), f"{label} cold"
             assert [s["nsplit"] for s in km.iteration_stats] == list(r1.nsplit), label
@@ -113,7 +111,6 @@ def test_kmeans_d128_pruned_path_matches_oracle(be, oracle, monkeypatch, k, n1, 
             km.train(x[n1:], init_centroids=km.centroids)
             assert np.array_equal(bits(km.centroids), bits(r2.centroids)), f"{label} warm"
             assert [s["nsplit"] for s in km.iteration_stats] == list(r2.nsplit), label
-    monkeypatch.delenv("AT_FILTER", raising=False)
 
 
 @pytest.mark.parametrize("n,k", [(2097152, 8192), (3000000, 16384)])

@@ -1,7 +1,9 @@
-"""The sharded k-means on real HIP kernels with world_size 2: two ranks share cuda:0 and exchange
-their partials through gloo (host-staged), which exercises the same host logic and the same
-kernels as one-rank-per-GPU under RCCL.  Result must equal the oracle's two-shard variant, bit for
-bit, on both ranks."""
+"""The sharded k-means on real HIP kernels with world_size 2.
+
+With two or more GPUs visible the ranks take one device each and exchange their partials over RCCL
+(torch.distributed backend "nccl"): the production path of an N-GPU run.  On a one-GPU box the two ranks
+share cuda:0 and exchange through gloo (host-staged), which exercises the same host logic and the same
+kernels.  Either way the result must equal the oracle's two-shard variant, bit for bit, on both ranks."""
 import os
 import socket
 import warnings
@@ -33,9 +35,14 @@ def _worker(rank, world, port, q):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    use_rccl = torch.cuda.device_count() >= world          # (counting devices does not initialise the GPU)
+    dev = rank if use_rccl else 0
+    torch.cuda.set_device(dev)
+    if use_rccl:   # the process group first: RCCL binds the rank to its device
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        torch.cuda.set_device(0)
         from audio_tokens_amd.ops import Kmeans
         from audio_tokens_amd.pipeline import DevicePipeline
         from audio_tokens_amd.synth import synth_clips
@@ -67,6 +74,7 @@ def _worker(rank, world, port, q):
                                  distributed=True).run(mine[:2], mine[2:])
             out["pipe_centroids"] = res.centroids.cpu().numpy()
             out["pipe_tokens"] = res.tokens_train.cpu().numpy()
+            out["backend"] = dist.get_backend()
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
@@ -83,6 +91,8 @@ def test_two_ranks_one_gpu(oracle, be):
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    import torch
+    assert res[0]["backend"] == res[1]["backend"] == ("nccl" if torch.cuda.device_count() >= 2 else "gloo")
     g = np.load(G / "kmeans.npz")
     assert np.array_equal(bits(res[0]["plain"]), bits(res[1]["plain"]))
     assert np.array_equal(bits(res[0]["plain"]), bits(g["d_centroids"]))

@@ -80,11 +80,11 @@ def test_assign_hinted_is_hint_independent(be, oracle, n, d, k):
                                               (50000, 128, 4096, False), (20000, 64, 2048, False),
                                               (33333, 128, 1500, False), (33333, 64, 1500, True), (25001, 64, 16384, False),
                                               (30001, 128, 16384, False)])   # (last: the shape of BASELINE configs[4])
-def test_assign_pruned_is_exact(be, oracle, monkeypatch, n, d, k, lds_kernel):
+def test_assign_pruned_is_exact(be, oracle, switches, n, d, k, lds_kernel):
     """at_assign_pruned_f32 == brute force, bit for bit, for good guesses (where it prunes), bad
     guesses, missing guesses and exact ties."""
     if lds_kernel:
-        monkeypatch.setenv("AT_PRUNE_KERNEL", "0")   # the LDS-DMA form of the d=64 kernel
+        switches(prune_kernel=0)   # the LDS-DMA form of the d=64 kernel
     rng = np.random.default_rng(n * 3 + d + k)
     # clustered data so that pruning actually happens
     centers = _unit_rows(rng, k, d, oracle)
@@ -382,17 +382,16 @@ def test_resample_matches_oracle(be, oracle, orig_freq, new_freq):
             assert np.abs(got[b] - want).max() <= tol
 
 
-def test_resample_kernels_agree_bitwise(be, monkeypatch):
+def test_resample_kernels_agree_bitwise(be, switches):
     """The LDS-tiled kernel and the plain one run the same ascending-k fma chain."""
     for orig_freq, new_freq, L in ((44100, 22050, 50001), (48000, 22050, 30011), (11025, 22050, 999),
                                    (96000, 22050, 40000), (16000, 22050, 16000)):
         w = torch.randn(3, L, device=be.device)
-        monkeypatch.delenv("AT_RESAMPLE_SIMPLE", raising=False)
+        switches(resample_simple=0)
         tiled = be.resample(w, orig_freq, new_freq)
-        monkeypatch.setenv("AT_RESAMPLE_SIMPLE", "1")
+        switches(resample_simple=1)
         plain = be.resample(w, orig_freq, new_freq)
         assert torch.equal(tiled, plain), (orig_freq, new_freq)
-    monkeypatch.delenv("AT_RESAMPLE_SIMPLE", raising=False)
 
 
 def test_resample_strided_rows_and_class(be, oracle):
@@ -454,7 +453,7 @@ def test_full_size_lloyd_shape_properties(be):
     assert int(torch.bincount(ids_d, minlength=k).sum()) == n
 
 
-def test_full_size_kmeans_is_independent_of_the_acceleration(be, monkeypatch):
+def test_full_size_kmeans_is_independent_of_the_acceleration(be, switches):
     """One FAISS-recipe training at the benchmark's size (2.1 M rows, 8192 clusters): the fp16-split
     filter + fused pre-pass + exact pruning must leave centroids and objectives exactly where the
     plain pruned fp32 sweep puts them, and the objective must not rise between Lloyd iterations."""
@@ -464,11 +463,8 @@ def test_full_size_kmeans_is_independent_of_the_acceleration(be, monkeypatch):
     wave = synth_clips(1218, L=220500, seed=99, device=be.device)
     x = be.logmel(wave, 22050, 512, 128, 64, frame_major=True, l2norm=True)[:2097152].contiguous()
     runs = {}
-    for label, env in (("filtered", {}), ("fp32", {"AT_FILTER": "0"})):
-        for key in ("AT_FILTER",):
-            monkeypatch.delenv(key, raising=False)
-        for key, val in env.items():
-            monkeypatch.setenv(key, val)
+    for label, use_filter in (("filtered", True), ("fp32", False)):
+        switches(filter=use_filter)
         km = Kmeans(64, 8192, niter=4, backend=be)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -476,20 +472,19 @@ def test_full_size_kmeans_is_independent_of_the_acceleration(be, monkeypatch):
             first = (km.centroids_device.clone(), [s["obj"] for s in km.iteration_stats], [s["nsplit"] for s in km.iteration_stats])
             km.train(x[:1000000], init_centroids=km.centroids_device)     # warm start: previous grouping, regrouped beside
         runs[label] = first + (km.centroids_device.clone(), [s["obj"] for s in km.iteration_stats])
-    monkeypatch.delenv("AT_FILTER", raising=False)
     (ca, oa, sa, wa, woa), (cb, ob, sb, wb, wob) = runs["filtered"], runs["fp32"]
     assert torch.equal(ca.view(torch.int32), cb.view(torch.int32)) and torch.equal(wa.view(torch.int32), wb.view(torch.int32))
     assert oa == ob and sa == sb and woa == wob
     assert all(later <= earlier * (1 + 1e-6) for earlier, later in zip(oa[1:], oa[2:]))   # (iteration 1 may repair empties)
 
 
-@pytest.mark.parametrize("env", [{"AT_FILTER_SCREEN": "0"}, {"AT_FILTER_FUSED": "0"}, {"AT_FILTER_NB": "4"},
-                                 {"AT_FILTER_NB": "2", "AT_FILTER_WPS2": "1"}, {"AT_DMIN_KERNEL": "0"},
-                                 {"AT_C2F_FUSED": "0"}, {"AT_FILTER": "0", "AT_PRUNE_NB": "1"}, {"AT_FILTER_SYNC": "1"}])
-def test_ab_switches_leave_the_bits_alone(be, oracle, monkeypatch, env):
-    """Every A/B switch of README.md selects another route to the same ids and distances."""
-    for key, val in env.items():
-        monkeypatch.setenv(key, val)
+@pytest.mark.parametrize("sw", [{"filter_screen": 0}, {"filter_fused": 0}, {"filter_nb": 4},
+                                {"filter_nb": 2, "filter_wps2": 1}, {"dmin_kernel": 0},
+                                {"c2f_fused": 0}, {"filter": 0, "prune_nb": 1}, {"filter": 0, "prune_nb": 4}, {"filter_sync": 1},
+                                {"assign_variant": 1}])
+def test_ab_switches_leave_the_bits_alone(be, oracle, switches, sw):
+    """Every A/B switch (include/at_debug.h, README.md) selects another route to the same ids and distances."""
+    switches(**sw)
     rng = np.random.default_rng(5)
     n, d, k = 70000, 64, 2048
     centers = _unit_rows(rng, k, d, oracle)

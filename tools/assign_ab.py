@@ -15,7 +15,7 @@ for (n, d, k) in shapes:
     times = {v: [] for v in variants}
     for rnd in range(4):
         for v in variants:
-            os.environ["AT_ASSIGN_VARIANT"] = str(v)
+            be.debug_set("assign_variant", v)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); ids, dis = be.assign(x, c); e1.record(); torch.cuda.synchronize()
             if rnd > 0: times[v].append(e0.elapsed_time(e1))
