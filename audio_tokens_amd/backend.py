@@ -250,6 +250,15 @@ class HipBackend(HostHelpers):
             _lib.check(self.lib.at_token_stats_f64(self.ctx.handle, _ptr(counts), k, _ptr(sc), _ptr(stok), _ptr(stats), self._stream()))
         return sc, stok, stats
 
+    def minmax_scale_clips(self, specs) -> torch.Tensor:
+        """specs [n_clips, ...] float32 on the device: every clip becomes (x - min) / (max - min), in place."""
+        assert specs.dtype == torch.float32 and specs.is_contiguous() and specs.device == self.device
+        if specs.shape[0]:
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.at_minmax_scale_clips_f32(self.ctx.handle, _ptr(specs), specs.shape[0],
+                                                              specs[0].numel(), self._stream()))
+        return specs
+
     def l2norm_rows(self, x, out=None) -> torch.Tensor:
         x = self._f32(x)
         assert x.dim() == 2

@@ -44,7 +44,52 @@ __global__ void __launch_bounds__(WG) l2norm_rows_kernel(const float* __restrict
     }
 }
 
+// Per-clip min-max scaling of a spectrogram (SpectrogramGenerator.normalize_spectrogram,
+// processors/spectrogram_generator.py:129-131): (spec - min) / (max - min) with torch's fp32 operations -- two
+// subtractions and one IEEE division per element.  One workgroup per clip: the reduction pass pulls the clip
+// (441 KB at 64 x 1723) through L2, the scaling pass reads it from there.  NaN propagates as in torch.min / max.
+__global__ void __launch_bounds__(1024) minmax_scale_kernel(float* __restrict__ x, long clip_elems) {
+    __shared__ float s_lo[16], s_hi[16];
+    __shared__ int s_nan[16];
+    float* p = x + (size_t)blockIdx.x * clip_elems;
+    const int t = threadIdx.x;
+    float lo = __builtin_inff(), hi = -__builtin_inff();
+    int nan = 0;
+    for (long e = t; e < clip_elems; e += 1024) {
+        const float v = p[e];
+        nan |= v != v;
+        lo = __builtin_fminf(lo, v);
+        hi = __builtin_fmaxf(hi, v);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = __builtin_fminf(lo, __shfl_xor(lo, off));
+        hi = __builtin_fmaxf(hi, __shfl_xor(hi, off));
+        nan |= __shfl_xor(nan, off);
+    }
+    if ((t & 63) == 0) { s_lo[t >> 6] = lo; s_hi[t >> 6] = hi; s_nan[t >> 6] = nan; }
+    __syncthreads();
+    for (int w = 0; w < 16; w++) {
+        lo = __builtin_fminf(lo, s_lo[w]);
+        hi = __builtin_fmaxf(hi, s_hi[w]);
+        nan |= s_nan[w];
+    }
+    if (nan) lo = hi = __builtin_nanf("");
+    const float range = hi - lo;
+    for (long e = t; e < clip_elems; e += 1024) p[e] = __fdiv_rn(p[e] - lo, range);
+}
+
 }  // namespace
+
+extern "C" int at_minmax_scale_clips_f32(at_ctx* ctx, float* x, int64_t n_clips, int64_t clip_elems, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AT_REQUIRE(ctx && n_clips >= 0 && n_clips <= 0x7fffffffL && clip_elems > 0, "at_minmax_scale_clips_f32: bad arguments");
+    if (n_clips == 0) return AT_OK;
+    AT_REQUIRE(x, "at_minmax_scale_clips_f32: null pointer");
+    AT_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(minmax_scale_kernel, dim3((unsigned)n_clips), dim3(1024), 0, stream, x, (long)clip_elems);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}
 
 extern "C" int at_l2norm_rows_f32(at_ctx* ctx, const float* x, int64_t n, int d, float* y,
                                   void* stream_) {

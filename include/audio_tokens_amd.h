@@ -109,6 +109,11 @@ int at_resample_f32(at_ctx* ctx, const float* wave, int64_t n_clips, int64_t L, 
  * numpy for finite inputs).  x == y is allowed. */
 int at_l2norm_rows_f32(at_ctx* ctx, const float* x, int64_t n, int d, float* y, void* stream);
 
+/* SpectrogramGenerator.normalize_spectrogram (processors/spectrogram_generator.py:129-131, config.normalize):
+ * every clip of clip_elems floats (a [n_mels][T] spectrogram) becomes (x - min) / (max - min), in place, with torch's
+ * fp32 operations (same bits as the reference's torch expression). */
+int at_minmax_scale_clips_f32(at_ctx* ctx, float* x, int64_t n_clips, int64_t clip_elems, void* stream);
+
 /* Nearest centroid under squared L2 (IndexFlatL2.search(x, 1)):
  *   dis(i,j) = max(0, (|x_i|^2 + |c_j|^2) - 2 <x_i, c_j>), all fp32, inner products and norms as
  *   ascending-index fmaf chains (v_mfma_f32_32x32x2_f32); ids[i] = lowest j attaining the minimum.

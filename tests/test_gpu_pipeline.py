@@ -253,3 +253,25 @@ def test_token_statistics_on_the_device_match_numpy_and_scipy(workdir, tmp_path,
     assert st.analyze_tokens(tokens[:1000].tolist())["total"] == 1000
     # and run() accumulates the histogram on the device while it tokenises
     assert st.token_statistics()["total"] == 0
+
+
+def test_normalize_option_is_one_kernel_with_torchs_bits(workdir, be):
+    """config.normalize = per-clip (spec - min) / (max - min); the batch kernel gives the bits of
+    the reference's torch expression (normalize_spectrogram), through populate_specs too."""
+    import dataclasses
+    from audio_tokens_amd.processors import SpectrogramGenerator
+    cfg, split, waves = workdir
+    specs = torch.randn(37, 64, 345, device=be.device) * 30 - 40
+    specs[5] = specs[5].abs()                      # another range
+    specs[9, 3, 7] = float("nan")                  # torch.min / max propagate NaN: the whole clip becomes NaN
+    want = torch.stack([SpectrogramGenerator.normalize_spectrogram(s) for s in specs])
+    got = be.minmax_scale_clips(specs.clone())
+    assert torch.equal(got[:9].view(torch.int32), want[:9].view(torch.int32))
+    assert torch.equal(got[10:].view(torch.int32), want[10:].view(torch.int32))
+    assert bool(torch.isnan(got[9]).all()) and bool(torch.isnan(want[9]).all())
+    plain = SpectrogramGenerator(cfg).populate_specs(split["train"][:5])
+    normed = SpectrogramGenerator(dataclasses.replace(cfg, normalize=True)).populate_specs(split["train"][:5])
+    for a, b in zip(plain, normed):
+        ref = SpectrogramGenerator.normalize_spectrogram(a["spec"])
+        assert torch.equal(b["spec"].view(torch.int32), ref.view(torch.int32))
+        assert float(b["spec"].min()) == 0.0 and float(b["spec"].max()) == 1.0
