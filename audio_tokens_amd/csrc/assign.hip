@@ -890,8 +890,8 @@ __global__ void __launch_bounds__(WG) prep_centroids_chunked_kernel(const float*
     }
 }
 
-template <int NB, int NA>
-__global__ void __launch_bounds__(WG, 2)
+template <int NB, int NA, int WPS>
+__global__ void __launch_bounds__(WG, WPS)
 assign_mfma_anyd_kernel(const float* __restrict__ X, long n, int d, int nchunks,
                         const float* __restrict__ img, int ntiles, long* __restrict__ ids,
                         float* __restrict__ dist) {
@@ -948,20 +948,16 @@ assign_mfma_anyd_kernel(const float* __restrict__ X, long n, int d, int nchunks,
     const int nstages = ntiles * nchunks;
     int ct = 0, ch = 0;
     f32x16 acc[NA][NB];
-    for (int s = 0; s < nstages; s++) {
-        const float* cur = smem + (s & 1) * BUF_F;
-        {
-            int nct = ct, nch = ch + 1;
-            if (nch == nchunks) { nch = 0; nct++; }
-            if (s + 1 < nstages) stage_dma(nct, nch, smem + ((s + 1) & 1) * BUF_F);
-        }
-        // this wave's x chunk (features ch*64 .. +63, zero past d) as the B operand
-        float xr[NB][DC / 2];
+    // A wave's x chunk (features chx*64 .. +63 of its 32*NB rows, zero past d) as the B operand.  Two register
+    // sets alternate: the chunk of stage s+1 is requested from L2 before the MFMAs of stage s are issued, so its
+    // latency runs beside them instead of in front of the next stage (round 1 reloaded it at the top of every stage
+    // and waited: 41-55 % of the fp32 MFMA peak at d = 640).
+    auto load_x = [&](int chx, float (&xr)[NB][DC / 2]) {
 #pragma unroll
         for (int b = 0; b < NB; b++) {
 #pragma unroll
             for (int q = 0; q < DC / 8; q++) {
-                const int f = ch * DC + 8 * q;
+                const int f = chx * DC + 8 * q;
                 f32x4 u = {0, 0, 0, 0}, v = {0, 0, 0, 0};
                 if (f < d) u = *reinterpret_cast<const f32x4*>(xrow[b] + f);          // d % 4 == 0
                 if (f + 4 < d) v = *reinterpret_cast<const f32x4*>(xrow[b] + f + 4);
@@ -969,6 +965,17 @@ assign_mfma_anyd_kernel(const float* __restrict__ X, long n, int d, int nchunks,
                 xr[b][4 * q + 1] = h ? u[3] : u[2];
                 xr[b][4 * q + 2] = h ? v[1] : v[0];
                 xr[b][4 * q + 3] = h ? v[3] : v[2];
+            }
+        }
+    };
+    auto stage = [&](int s, const float (&xr)[NB][DC / 2], float (&xr_next)[NB][DC / 2]) {
+        const float* cur = smem + (s & 1) * BUF_F;
+        {
+            int nct = ct, nch = ch + 1;
+            if (nch == nchunks) { nch = 0; nct++; }
+            if (s + 1 < nstages) {
+                stage_dma(nct, nch, smem + ((s + 1) & 1) * BUF_F);
+                load_x(nch, xr_next);
             }
         }
 #pragma unroll
@@ -1004,6 +1011,12 @@ assign_mfma_anyd_kernel(const float* __restrict__ X, long n, int d, int nchunks,
         }
         if (++ch == nchunks) { ch = 0; ct++; }
         __syncthreads();
+    };
+    float xrA[NB][DC / 2], xrB[NB][DC / 2];
+    load_x(0, xrA);
+    for (int s = 0; s < nstages; s += 2) {
+        stage(s, xrA, xrB);
+        if (s + 1 < nstages) stage(s + 1, xrB, xrA);
     }
 
 #pragma unroll
@@ -1116,6 +1129,30 @@ int launch_mfma(at_ctx* ctx, const float* x, int64_t n, const float* c, int k, i
 }
 
 
+template <int NB, int NA, int WPS>
+static int launch_anyd(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k, int64_t* ids, float* dist,
+                       hipStream_t stream) {
+    const int nchunks = (d + DC - 1) / DC;
+    const int ntiles = (k + tile_rows(NA) - 1) / tile_rows(NA);
+    const size_t tile_f = (size_t)tile_rows(NA) * DC * nchunks + CN_PAD;
+    float* img = static_cast<float*>(at_ws(ctx, WS_CENT_IMG, sizeof(float) * ntiles * tile_f, stream));
+    if (!img) return AT_E_NOMEM;
+    hipLaunchKernelGGL(prep_centroids_chunked_kernel, dim3(ntiles), dim3(WG), 0, stream, c, k, d, nchunks, NA, img);
+    AT_LAUNCH_CHECK();
+    const size_t lds = 2 * sizeof(float) * (tile_rows(NA) * DC + CN_PAD);
+    static bool attr_set = false;
+    if (!attr_set) {
+        AT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&assign_mfma_anyd_kernel<NB, NA, WPS>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int64_t rows_per_wg = 4 * 32 * NB;
+    hipLaunchKernelGGL((assign_mfma_anyd_kernel<NB, NA, WPS>), dim3((unsigned)((n + rows_per_wg - 1) / rows_per_wg)),
+                       dim3(WG), lds, stream, x, (long)n, d, nchunks, img, ntiles, reinterpret_cast<long*>(ids), dist);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}
+
 }  // namespace
 
 extern "C" int at_assign_f32(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k,
@@ -1151,22 +1188,13 @@ extern "C" int at_assign_f32(at_ctx* ctx, const float* x, int64_t n, int d, cons
     }
 
     if (d % 4 == 0 && at_aligned16(x) && ctx->dbg.assign_variant != 2) {
-        constexpr int NB = 2, NA = 2;
-        const int nchunks = (d + DC - 1) / DC;
-        const int ntiles = (k + tile_rows(NA) - 1) / tile_rows(NA);
-        const size_t tile_f = (size_t)tile_rows(NA) * DC * nchunks + CN_PAD;
-        float* img = static_cast<float*>(at_ws(ctx, WS_CENT_IMG, sizeof(float) * ntiles * tile_f, stream));
-        if (!img) return AT_E_NOMEM;
-        hipLaunchKernelGGL(prep_centroids_chunked_kernel, dim3(ntiles), dim3(WG), 0, stream, c, k, d, nchunks,
-                           NA, img);
-        AT_LAUNCH_CHECK();
-        const size_t lds = 2 * sizeof(float) * (tile_rows(NA) * DC + CN_PAD);
-        const int64_t rows_per_wg = 4 * 32 * NB;
-        hipLaunchKernelGGL((assign_mfma_anyd_kernel<NB, NA>), dim3((unsigned)((n + rows_per_wg - 1) / rows_per_wg)),
-                           dim3(WG), lds, stream, x, (long)n, d, nchunks, img, ntiles,
-                           reinterpret_cast<long*>(ids), dist);
-        AT_LAUNCH_CHECK();
-        return AT_OK;
+        // shapes (assign_variant: A/B aid): 0 = two row tiles x two centroid tiles per wave at one wave per SIMD (both
+        // x-chunk register sets fit); 4 = one row tile at two waves per SIMD
+        const int v = ctx->dbg.assign_variant;
+        if (v == 4) return launch_anyd<1, 2, 2>(ctx, x, n, d, c, k, ids, dist, stream);
+        if (v == 5) return launch_anyd<1, 2, 3>(ctx, x, n, d, c, k, ids, dist, stream);
+        if (v == 6) return launch_anyd<2, 2, 1>(ctx, x, n, d, c, k, ids, dist, stream);
+        return launch_anyd<1, 4, 2>(ctx, x, n, d, c, k, ids, dist, stream);
     }
 
     float* cn = static_cast<float*>(at_ws(ctx, WS_CENT_IMG, sizeof(float) * (size_t)k, stream));

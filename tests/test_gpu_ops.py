@@ -243,6 +243,24 @@ def test_assign_generic_d(be, oracle, d, k):
     assert np.array_equal(bits(dis.cpu().numpy()), bits(dis_o))
 
 
+@pytest.mark.parametrize("variant", [0, 4, 5, 6])
+def test_assign_anyd_shapes_at_d640(be, oracle, switches, variant):
+    """use_convolution's d = 640 (ten 64-feature chunks, the x chunk of the next stage prefetched into a second
+    register set): every shape of the chunked MFMA kernel against the oracle, including a k that leaves the last
+    128-centroid tile mostly empty and exact duplicates."""
+    switches(assign_variant=variant)
+    rng = np.random.default_rng(640 + variant)
+    n, d, k = 3000, 640, 700
+    x = _unit_rows(rng, n, d, oracle)
+    c = _unit_rows(rng, k, d, oracle)
+    c[600:620] = c[0:20]
+    x[:20] = c[600:620]
+    ids_o, dis_o = oracle.assign(x, c)
+    ids, dis = be.assign(x, c)
+    assert np.array_equal(ids.cpu().numpy(), ids_o)
+    assert np.array_equal(bits(dis.cpu().numpy()), bits(dis_o))
+
+
 @pytest.mark.parametrize("n,d", [(1, 64), (1000, 64), (777, 128), (300, 3), (100, 130), (64, 640), (5000, 20)])
 def test_l2norm_rows_bit_exact_vs_numpy(be, n, d):
     rng = np.random.default_rng(n + d)
