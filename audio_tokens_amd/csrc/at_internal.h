@@ -46,6 +46,9 @@ enum at_ws_slot {
     WS_TSTAT_IOTA,     // at_token_stats_f64: token ids before the sort, rocprim temp storage
     WS_TSTAT_TMP,
     WS_MT_RAW,         // at_mt_cached_draws: the resident start of the mt19937(1234) stream + the state behind it
+    WS_LONG_PRED,      // centroid_accum: the long clusters of the last call (the next call's early set) + generation marks
+    WS_LONG_EARLY,     // centroid_accum: block counts / bases and the member lists of the early set
+    WS_LONG_LATE,      // centroid_accum: long clusters left to the pass behind the sort
     WS_NSLOTS
 };
 
@@ -106,6 +109,8 @@ struct at_ctx {
     hipStream_t side_stream;             // centroid_accum: long member lists beside the short ones
     hipEvent_t side_ev[2];
     int defer_join, join_pending;        // at_centroid_accum_defer / at_centroid_accum_join
+    int long_pred_k;                     // table size WS_LONG_PRED was last used with
+    unsigned long_gen;                   // generation of its 'summed early' marks
     // what at_group_min_dist_f32 left in WS_CENT_IMG16 / WS_FILTER_MISC[0]; a sweep may reuse it when its
     // caller vouches (prepass_done bit 1) that the centroids are unchanged
     const float* img16_c;

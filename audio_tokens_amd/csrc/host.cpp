@@ -154,6 +154,7 @@ void* at_ws(at_ctx* ctx, int slot, size_t bytes, hipStream_t stream) {
     if (slot == WS_LOGMEL_FB) { ctx->fb_sr = ctx->fb_nfft = ctx->fb_nmels = 0; ctx->fb_user = nullptr; }
     if (slot == WS_RESAMPLE_TAPS) ctx->rs_orig = ctx->rs_new = 0;
     if (slot == WS_MT_RAW) ctx->mt_have = 0;
+    if (slot == WS_LONG_PRED) ctx->long_pred_k = 0;
     return p;
 }
 

@@ -100,33 +100,47 @@ __global__ void __launch_bounds__(WG) centroid_accum_kernel(const float* __restr
 #pragma unroll
     for (int v = 0; v < VEC; v++) acc[v] = 0.0f;
 
+    // Rows are fetched eight at a time into one of two register sets: the loads of batch i+1 are in flight while
+    // batch i is added (in member order: one dependent chain per feature, as the contract says), and the member
+    // indices of the next 64 rows are fetched while this block of 64 is summed (262 -> 215 us at 2 M x 64).
+    auto fetch = [&](uint32_t mine, uint32_t m, uint32_t cnt, float (&t)[8][VEC]) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t src = __builtin_amdgcn_readlane(mine, (m + u) & 63);
+            const bool ok = (m + u < cnt) && live;
+            if constexpr (VEC == 4) {
+                float4 q = ok ? *reinterpret_cast<const float4*>(x + (size_t)src * d + f0) : make_float4(0, 0, 0, 0);
+                t[u][0] = q.x; t[u][1] = q.y; t[u][2] = q.z; t[u][3] = q.w;
+            } else if constexpr (VEC == 2) {
+                float2 q = ok ? *reinterpret_cast<const float2*>(x + (size_t)src * d + f0) : make_float2(0, 0);
+                t[u][0] = q.x; t[u][1] = q.y;
+            } else {
+                t[u][0] = ok ? x[(size_t)src * d + f0] : 0.0f;
+            }
+        }
+    };
+    auto add = [&](uint32_t m, uint32_t cnt, const float (&t)[8][VEC]) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (m + u < cnt) {  // wave-uniform: the tail adds nothing at all
+#pragma unroll
+                for (int v = 0; v < VEC; v++) acc[v] += t[u][v];
+            }
+        }
+    };
+    uint32_t mine_next = (beg < end && lane < min(64u, end - beg)) ? order[beg + lane] : 0u;
     for (uint32_t base = beg; base < end; base += 64) {
         const uint32_t cnt = min(64u, end - base);
-        const uint32_t mine = lane < cnt ? order[base + lane] : 0u;
-        for (uint32_t m = 0; m < cnt; m += 8) {
-            float t[8][VEC];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint32_t src = __builtin_amdgcn_readlane(mine, (m + u) & 63);
-                const bool ok = (m + u < cnt) && live;
-                if constexpr (VEC == 4) {
-                    float4 q = ok ? *reinterpret_cast<const float4*>(x + (size_t)src * d + f0)
-                                  : make_float4(0, 0, 0, 0);
-                    t[u][0] = q.x; t[u][1] = q.y; t[u][2] = q.z; t[u][3] = q.w;
-                } else if constexpr (VEC == 2) {
-                    float2 q = ok ? *reinterpret_cast<const float2*>(x + (size_t)src * d + f0)
-                                  : make_float2(0, 0);
-                    t[u][0] = q.x; t[u][1] = q.y;
-                } else {
-                    t[u][0] = ok ? x[(size_t)src * d + f0] : 0.0f;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                if (m + u < cnt) {  // wave-uniform: the tail adds nothing at all
-#pragma unroll
-                    for (int v = 0; v < VEC; v++) acc[v] += t[u][v];
-                }
+        const uint32_t mine = mine_next;
+        if (base + 64 < end) mine_next = lane < min(64u, end - base - 64) ? order[base + 64 + lane] : 0u;
+        float tA[8][VEC], tB[8][VEC];
+        fetch(mine, 0, cnt, tA);
+        for (uint32_t m = 0; m < cnt; m += 16) {
+            if (m + 8 < cnt) fetch(mine, m + 8, cnt, tB);
+            add(m, cnt, tA);
+            if (m + 8 < cnt) {
+                if (m + 16 < cnt) fetch(mine, m + 16, cnt, tA);
+                add(m + 8, cnt, tB);
             }
         }
     }
@@ -148,20 +162,34 @@ constexpr int LONG_CHUNK = 2048;                       // members per ring buffe
 constexpr int LONG_LOADERS = WG - 64;                  // threads that load
 constexpr int LONG_PER_THREAD = (LONG_CHUNK + LONG_LOADERS - 1) / LONG_LOADERS;
 
+constexpr int EARLY_MAX = 8;        // long clusters whose member lists are built ahead of the sort
+constexpr int EARLY_ROWS = 4096;    // rows per workgroup of the ordered compaction
+
+// early != 0: list `slot` of the early lists (cluster cluster_of[slot], members early_offsets[slot] ..); marks the
+// cluster done[c] = gen.  early == 0: the regular pass over all clusters after the sort; records every long cluster
+// in pred (the next call's early set) and skips those the early pass has already summed.
 __global__ void __launch_bounds__(WG) centroid_accum_long_kernel(const float* __restrict__ x, int d,
                                                                  const uint32_t* __restrict__ order,
                                                                  const uint32_t* __restrict__ offsets,
                                                                  uint32_t long_list,
                                                                  float* __restrict__ sums,
-                                                                 float* __restrict__ counts) {
+                                                                 float* __restrict__ counts, int k, int early,
+                                                                 const int* __restrict__ cluster_of,
+                                                                 const int* __restrict__ n_slots,
+                                                                 unsigned* __restrict__ done, unsigned gen) {
     // feature-major ring: ring[buffer][feature][member], so an adder lane reads four consecutive members of
     // its feature with one 16-byte LDS read
     __shared__ __attribute__((aligned(16))) float ring[2][4][LONG_CHUNK];
-    const int c = blockIdx.x;
+    // early: slot = blockIdx.x of the early lists.  Regular pass: the workgroups stride over the late list
+    // (cluster_of[0] = its length, clusters behind it), offsets indexed by cluster.
+    const int n_slot = early ? min(*n_slots, EARLY_MAX) : cluster_of[0];
     const int piece = blockIdx.y;  // features 4*piece .. 4*piece+3
-    const uint32_t beg = offsets[c], end = offsets[c + 1];
+    for (int slot = blockIdx.x; slot < n_slot; slot += gridDim.x) {
+    const int c = early ? cluster_of[slot] : cluster_of[1 + slot];
+    if (c < 0 || c >= k) continue;
+    const uint32_t beg = early ? offsets[slot] : offsets[c], end = early ? offsets[slot + 1] : offsets[c + 1];
     const uint32_t len = end - beg;
-    if (len <= long_list) return;  // uniform for the workgroup
+    if (len <= long_list) continue;  // uniform for the workgroup
     const int tid = threadIdx.x;
     const bool adder = tid < 64;
     const uint32_t nchunks = (len + LONG_CHUNK - 1) / LONG_CHUNK;
@@ -239,7 +267,136 @@ __global__ void __launch_bounds__(WG) centroid_accum_long_kernel(const float* __
         __syncthreads();
     }
     if (tid < 4) sums[(size_t)c * d + 4 * piece + tid] = acc;
-    if (tid == 0 && piece == 0) counts[c] = (float)len;
+    if (tid == 0 && piece == 0) {
+        counts[c] = (float)len;
+        if (early) done[c] = gen;
+    }
+    __syncthreads();   // (the ring is reused by the next list)
+    }  // slot
+}
+
+// ---- member lists of the (predicted) long clusters, ahead of the sort -----------------------------------------
+// A list of tens of thousands of members is one dependent chain of adds, 300 us at 2 M rows: as long as everything
+// else of the accumulation together, and it used to start only after the sort.  The clusters that were long in
+// the previous call (a Lloyd iteration changes 2 % of the assignments) get their lists from an ordered compaction
+// of ids instead -- count per 4096-row block, scan, ordered write: three small launches -- so their chains run
+// beside the sort.  Whatever the prediction, a list built here is exactly the cluster's members in ascending row
+// order; a cluster that is not long after all is left to the short-list kernel.
+__global__ void __launch_bounds__(WG) early_count_kernel(const long* __restrict__ ids, long n, const int* __restrict__ pred,
+                                                         const int* __restrict__ pred_n, int nblk,
+                                                         uint32_t* __restrict__ blockcnt) {
+    __shared__ uint32_t cnt[EARLY_MAX];
+    const int np = min(*pred_n, EARLY_MAX);
+    if (threadIdx.x < EARLY_MAX) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    if (np > 0) {
+        long want[EARLY_MAX];
+#pragma unroll
+        for (int m = 0; m < EARLY_MAX; m++) want[m] = m < np ? (long)pred[m] : -2L;
+        const long r0 = (long)blockIdx.x * EARLY_ROWS;
+        uint32_t mine[EARLY_MAX] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = threadIdx.x; i < EARLY_ROWS; i += WG) {
+            const long r = r0 + i;
+            if (r < n) {
+                const long id = ids[r];
+#pragma unroll
+                for (int m = 0; m < EARLY_MAX; m++) mine[m] += id == want[m];
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < EARLY_MAX; m++) {
+            uint32_t v = mine[m];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if ((threadIdx.x & 63) == 0 && v) atomicAdd(&cnt[m], v);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < EARLY_MAX) blockcnt[(size_t)threadIdx.x * nblk + blockIdx.x] = cnt[threadIdx.x];
+}
+
+// one workgroup: blockbase[m][b] = members of pred[m] in blocks before b; eoff[m] = start of list m (lists back to back)
+__global__ void __launch_bounds__(1024) early_scan_kernel(const uint32_t* __restrict__ blockcnt, int nblk,
+                                                          uint32_t* __restrict__ blockbase, uint32_t* __restrict__ eoff) {
+    __shared__ uint32_t part[EARLY_MAX][1024];
+    __shared__ uint32_t total[EARLY_MAX];
+    const int t = threadIdx.x;
+    const int per = (nblk + 1023) / 1024;
+    const int lo = min(nblk, t * per), hi = min(nblk, lo + per);
+#pragma unroll
+    for (int m = 0; m < EARLY_MAX; m++) {
+        uint32_t s = 0;
+        for (int b = lo; b < hi; b++) s += blockcnt[(size_t)m * nblk + b];
+        part[m][t] = s;
+    }
+    __syncthreads();
+    if (t < EARLY_MAX) {   // (eight serial scans of 1024 side by side)
+        uint32_t run = 0;
+        for (int i = 0; i < 1024; i++) { const uint32_t v = part[t][i]; part[t][i] = run; run += v; }
+        total[t] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < EARLY_MAX; m++) {
+        uint32_t run = part[m][t];
+        for (int b = lo; b < hi; b++) {
+            blockbase[(size_t)m * nblk + b] = run;
+            run += blockcnt[(size_t)m * nblk + b];
+        }
+    }
+    if (t == 0) {
+        uint32_t run = 0;
+        for (int m = 0; m < EARLY_MAX; m++) { eoff[m] = run; run += total[m]; }
+        eoff[EARLY_MAX] = run;
+    }
+}
+
+// After the sort: every long cluster goes into the next call's early set (pred), those the early pass has not summed
+// into late[] (late[0] = how many) -- so that the regular long pass is a handful of workgroups, not k x d/4 of which
+// all but a few leave at once (65-95 us of dispatch at k = 8192).
+__global__ void __launch_bounds__(WG) long_detect_kernel(const uint32_t* __restrict__ offsets, int k, uint32_t long_list,
+                                                         const unsigned* __restrict__ done, unsigned gen,
+                                                         int* __restrict__ pred, int* __restrict__ pred_n,
+                                                         int* __restrict__ late) {
+    const int c = blockIdx.x * WG + threadIdx.x;
+    if (c >= k) return;
+    if (offsets[c + 1] - offsets[c] <= long_list) return;
+    const int slot = atomicAdd(pred_n, 1);
+    if (slot < EARLY_MAX) pred[slot] = c;
+    if (done[c] != gen) late[1 + atomicAdd(&late[0], 1)] = c;
+}
+
+__global__ void __launch_bounds__(WG) early_write_kernel(const long* __restrict__ ids, long n, const int* __restrict__ pred,
+                                                         const int* __restrict__ pred_n, int nblk,
+                                                         const uint32_t* __restrict__ blockbase,
+                                                         const uint32_t* __restrict__ eoff, uint32_t* __restrict__ lists) {
+    __shared__ uint32_t wave_cnt[WG / 64];
+    __shared__ uint32_t run[EARLY_MAX];
+    const int np = min(*pred_n, EARLY_MAX);
+    if (np <= 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < EARLY_MAX) run[threadIdx.x] = eoff[threadIdx.x] + blockbase[(size_t)threadIdx.x * nblk + blockIdx.x];
+    __syncthreads();
+    const long r0 = (long)blockIdx.x * EARLY_ROWS;
+    for (int i0 = 0; i0 < EARLY_ROWS; i0 += WG) {        // 256 consecutive rows per round, in row order
+        const long r = r0 + i0 + threadIdx.x;
+        const long id = r < n ? ids[r] : -1L;
+        for (int m = 0; m < np; m++) {
+            const bool hit = id == (long)pred[m];
+            const unsigned long long b = __ballot(hit);
+            if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(b);
+            __syncthreads();
+            uint32_t before = 0, all = 0;
+#pragma unroll
+            for (int w = 0; w < WG / 64; w++) {
+                before += w < wave ? wave_cnt[w] : 0u;
+                all += wave_cnt[w];
+            }
+            if (hit) lists[run[m] + before + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)r;
+            __syncthreads();
+            if (threadIdx.x == 0) run[m] += all;
+            __syncthreads();
+        }
+    }
 }
 
 __global__ void __launch_bounds__(WG) centroid_finalize_kernel(const float* __restrict__ sums_parts,
@@ -376,6 +533,44 @@ int at_centroid_accum_f32(at_ctx* ctx, const float* x, int64_t n, int d, const i
     uint32_t* offsets = static_cast<uint32_t*>(at_ws(ctx, WS_SEG_OFFSETS, ((size_t)k + 2) * 4, stream));
     if (!keys_a || !keys_b || !vals_a || !vals_b || !offsets) return AT_E_NOMEM;
 
+    // (decided before anything is queued: the early lists of the long clusters run on the side stream beside the sort)
+    const bool al_x = at_aligned16(x);
+    const bool early_ok = d % 4 == 0 && al_x && n > 2048;
+    if (early_ok) {
+        if (!ctx->side_stream) {
+            AT_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+            AT_HIP(hipEventCreateWithFlags(&ctx->side_ev[0], hipEventDisableTiming));
+            AT_HIP(hipEventCreateWithFlags(&ctx->side_ev[1], hipEventDisableTiming));
+        }
+        int* pw = static_cast<int*>(at_ws(ctx, WS_LONG_PRED, ((size_t)k + 16) * 4, stream));
+        const int nblk = (int)((n + EARLY_ROWS - 1) / EARLY_ROWS);
+        uint32_t* ew = static_cast<uint32_t*>(at_ws(ctx, WS_LONG_EARLY, ((size_t)2 * EARLY_MAX * nblk + EARLY_MAX + 1 + nn) * 4, stream));
+        if (!pw || !ew) return AT_E_NOMEM;
+        if (ctx->long_pred_k != k) {
+            AT_HIP(hipMemsetAsync(pw, 0, ((size_t)k + 16) * 4, stream));
+            ctx->long_pred_k = k;
+            ctx->long_gen = 0;
+        }
+        uint32_t* blockcnt = ew;
+        uint32_t* blockbase = ew + (size_t)EARLY_MAX * nblk;
+        uint32_t* eoff = blockbase + (size_t)EARLY_MAX * nblk;
+        uint32_t* lists = eoff + EARLY_MAX + 1;
+        const unsigned gen = ctx->long_gen + 1;   // (the regular pass below takes the same generation)
+        AT_HIP(hipEventRecord(ctx->side_ev[0], stream));          // ids (and the marks) are ready
+        AT_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->side_ev[0], 0));
+        hipStream_t ss = ctx->side_stream;
+        hipLaunchKernelGGL(early_count_kernel, dim3(nblk), dim3(WG), 0, ss, reinterpret_cast<const long*>(ids), (long)n, pw + 1, pw,
+                           nblk, blockcnt);
+        hipLaunchKernelGGL(early_scan_kernel, dim3(1), dim3(1024), 0, ss, blockcnt, nblk, blockbase, eoff);
+        hipLaunchKernelGGL(early_write_kernel, dim3(nblk), dim3(WG), 0, ss, reinterpret_cast<const long*>(ids), (long)n, pw + 1, pw,
+                           nblk, blockbase, eoff, lists);
+        hipLaunchKernelGGL(centroid_accum_long_kernel, dim3(EARLY_MAX, d / 4), dim3(WG), 0, ss, x, d, lists, eoff, 2048u, sums,
+                           counts, k, 1, pw + 1, pw, reinterpret_cast<unsigned*>(pw + 16), gen);
+        AT_LAUNCH_CHECK();
+        // the regular pass rebuilds the prediction: its counter starts from zero once the early pass has read it
+        AT_HIP(hipMemsetAsync(pw, 0, 4, ss));
+    }
+
     const uint32_t* order = vals_a;
     const uint32_t* sorted_keys = keys_a;
     if (n > 0) {
@@ -413,16 +608,27 @@ int at_centroid_accum_f32(at_ctx* ctx, const float* x, int64_t n, int d, const i
     // kernel that handles all the other clusters.
     const bool have_long = long_ok && n > (int64_t)long_list;
     if (have_long) {
-        if (!ctx->side_stream) {
-            AT_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
-            AT_HIP(hipEventCreateWithFlags(&ctx->side_ev[0], hipEventDisableTiming));
-            AT_HIP(hipEventCreateWithFlags(&ctx->side_ev[1], hipEventDisableTiming));
-        }
-        AT_HIP(hipEventRecord(ctx->side_ev[0], stream));
+        AT_HIP(hipEventRecord(ctx->side_ev[0], stream));          // sorted lists and offsets are ready
         AT_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->side_ev[0], 0));
-        // (workgroups of short clusters exit at once; gridDim.y = feature slices)
-        hipLaunchKernelGGL(centroid_accum_long_kernel, dim3(k, d / 4), dim3(WG), 0, ctx->side_stream, x, d, order,
-                           offsets, long_list, sums, counts);
+        // pred / pred_n / done live in WS_LONG_PRED: [0] n predicted, [1..8] their clusters, then k generation marks
+        int* pw = static_cast<int*>(at_ws(ctx, WS_LONG_PRED, ((size_t)k + 16) * 4, stream));
+        if (!pw) return AT_E_NOMEM;
+        if (ctx->long_pred_k != k) {   // fresh (or another table size): no predictions, no marks
+            AT_HIP(hipMemsetAsync(pw, 0, ((size_t)k + 16) * 4, stream));
+            ctx->long_pred_k = k;
+            ctx->long_gen = 0;
+        }
+        const unsigned gen = ++ctx->long_gen;
+        int* pred_n = pw;
+        int* pred = pw + 1;
+        unsigned* done = reinterpret_cast<unsigned*>(pw + 16);
+        int* late = static_cast<int*>(at_ws(ctx, WS_LONG_LATE, ((size_t)k + 1) * 4, stream));
+        if (!late) return AT_E_NOMEM;
+        AT_HIP(hipMemsetAsync(late, 0, 4, ctx->side_stream));
+        hipLaunchKernelGGL(long_detect_kernel, dim3((k + WG - 1) / WG), dim3(WG), 0, ctx->side_stream, offsets, k, long_list,
+                           done, gen, pred, pred_n, late);
+        hipLaunchKernelGGL(centroid_accum_long_kernel, dim3(32, d / 4), dim3(WG), 0, ctx->side_stream, x, d, order,
+                           offsets, long_list, sums, counts, k, 0, late, nullptr, done, gen);
         AT_LAUNCH_CHECK();
         AT_HIP(hipEventRecord(ctx->side_ev[1], ctx->side_stream));
     }
