@@ -49,6 +49,7 @@ enum at_ws_slot {
     WS_LONG_PRED,      // centroid_accum: the long clusters of the last call (the next call's early set) + generation marks
     WS_LONG_EARLY,     // centroid_accum: block counts / bases and the member lists of the early set
     WS_LONG_LATE,      // centroid_accum: long clusters left to the pass behind the sort
+    WS_BUCKETS,        // centroid_accum bucket path: counts, cursors, the list of long clusters
     WS_NSLOTS
 };
 
@@ -77,6 +78,7 @@ struct at_debug {
     int filter_wps2;      // AT_FILTER_WPS2      1 = two waves per SIMD in the Lloyd-sized filter sweeps
     int dmin_kernel;      // AT_DMIN_KERNEL      0 = fp32 vector-ALU kernel for the centroid-to-group bounds
     int resample_simple;  // AT_RESAMPLE_SIMPLE  1 = one-thread-per-sample resampler
+    int accum_buckets;    // AT_ACCUM_BUCKETS    0 = member lists by radix sort (the only form for k > 16 384)
 };
 
 struct at_ctx {
@@ -109,6 +111,7 @@ struct at_ctx {
     hipStream_t side_stream;             // centroid_accum: long member lists beside the short ones
     hipEvent_t side_ev[2];
     int defer_join, join_pending;        // at_centroid_accum_defer / at_centroid_accum_join
+    int buckets_k;                       // table size WS_BUCKETS was last zeroed for
     int long_pred_k;                     // table size WS_LONG_PRED was last used with
     unsigned long_gen;                   // generation of its 'summed early' marks
     // what at_group_min_dist_f32 left in WS_CENT_IMG16 / WS_FILTER_MISC[0]; a sweep may reuse it when its

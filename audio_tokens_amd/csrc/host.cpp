@@ -41,6 +41,7 @@ const DebugField kDebugFields[] = {
     {"filter_wps2", "AT_FILTER_WPS2", &at_debug::filter_wps2, 0},
     {"dmin_kernel", "AT_DMIN_KERNEL", &at_debug::dmin_kernel, 1},
     {"resample_simple", "AT_RESAMPLE_SIMPLE", &at_debug::resample_simple, 0},
+    {"accum_buckets", "AT_ACCUM_BUCKETS", &at_debug::accum_buckets, 1},
 };
 }  // namespace
 
@@ -155,6 +156,7 @@ void* at_ws(at_ctx* ctx, int slot, size_t bytes, hipStream_t stream) {
     if (slot == WS_RESAMPLE_TAPS) ctx->rs_orig = ctx->rs_new = 0;
     if (slot == WS_MT_RAW) ctx->mt_have = 0;
     if (slot == WS_LONG_PRED) ctx->long_pred_k = 0;
+    if (slot == WS_BUCKETS) ctx->buckets_k = 0;
     return p;
 }
 

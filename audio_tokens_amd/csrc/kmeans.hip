@@ -162,7 +162,7 @@ constexpr int LONG_CHUNK = 2048;                       // members per ring buffe
 constexpr int LONG_LOADERS = WG - 64;                  // threads that load
 constexpr int LONG_PER_THREAD = (LONG_CHUNK + LONG_LOADERS - 1) / LONG_LOADERS;
 
-constexpr int EARLY_MAX = 8;        // long clusters whose member lists are built ahead of the sort
+constexpr int EARLY_MAX = 16;       // long clusters whose member lists come from the ordered compaction
 constexpr int EARLY_ROWS = 4096;    // rows per workgroup of the ordered compaction
 
 // early != 0: list `slot` of the early lists (cluster cluster_of[slot], members early_offsets[slot] ..); marks the
@@ -176,15 +176,16 @@ __global__ void __launch_bounds__(WG) centroid_accum_long_kernel(const float* __
                                                                  float* __restrict__ counts, int k, int early,
                                                                  const int* __restrict__ cluster_of,
                                                                  const int* __restrict__ n_slots,
-                                                                 unsigned* __restrict__ done, unsigned gen) {
+                                                                 unsigned* __restrict__ done, unsigned gen,
+                                                                 int slot0 = 0, int slot1 = 0x7fffffff) {
     // feature-major ring: ring[buffer][feature][member], so an adder lane reads four consecutive members of
     // its feature with one 16-byte LDS read
     __shared__ __attribute__((aligned(16))) float ring[2][4][LONG_CHUNK];
     // early: slot = blockIdx.x of the early lists.  Regular pass: the workgroups stride over the late list
     // (cluster_of[0] = its length, clusters behind it), offsets indexed by cluster.
-    const int n_slot = early ? min(*n_slots, EARLY_MAX) : cluster_of[0];
+    const int n_slot = min(early ? min(*n_slots, EARLY_MAX) : cluster_of[0], slot1);   // (list mode: slots [slot0, slot1))
     const int piece = blockIdx.y;  // features 4*piece .. 4*piece+3
-    for (int slot = blockIdx.x; slot < n_slot; slot += gridDim.x) {
+    for (int slot = slot0 + blockIdx.x; slot < n_slot; slot += gridDim.x) {
     const int c = early ? cluster_of[slot] : cluster_of[1 + slot];
     if (c < 0 || c >= k) continue;
     const uint32_t beg = early ? offsets[slot] : offsets[c], end = early ? offsets[slot + 1] : offsets[c + 1];
@@ -269,7 +270,7 @@ __global__ void __launch_bounds__(WG) centroid_accum_long_kernel(const float* __
     if (tid < 4) sums[(size_t)c * d + 4 * piece + tid] = acc;
     if (tid == 0 && piece == 0) {
         counts[c] = (float)len;
-        if (early) done[c] = gen;
+        if (early && done) done[c] = gen;
     }
     __syncthreads();   // (the ring is reused by the next list)
     }  // slot
@@ -294,7 +295,9 @@ __global__ void __launch_bounds__(WG) early_count_kernel(const long* __restrict_
 #pragma unroll
         for (int m = 0; m < EARLY_MAX; m++) want[m] = m < np ? (long)pred[m] : -2L;
         const long r0 = (long)blockIdx.x * EARLY_ROWS;
-        uint32_t mine[EARLY_MAX] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint32_t mine[EARLY_MAX];
+#pragma unroll
+        for (int m = 0; m < EARLY_MAX; m++) mine[m] = 0;
         for (int i = threadIdx.x; i < EARLY_ROWS; i += WG) {
             const long r = r0 + i;
             if (r < n) {
@@ -368,13 +371,18 @@ __global__ void __launch_bounds__(WG) long_detect_kernel(const uint32_t* __restr
 __global__ void __launch_bounds__(WG) early_write_kernel(const long* __restrict__ ids, long n, const int* __restrict__ pred,
                                                          const int* __restrict__ pred_n, int nblk,
                                                          const uint32_t* __restrict__ blockbase,
-                                                         const uint32_t* __restrict__ eoff, uint32_t* __restrict__ lists) {
+                                                         const uint32_t* __restrict__ eoff, uint32_t* __restrict__ lists,
+                                                         const uint32_t* __restrict__ seg_offsets) {
+    // list m starts at eoff[m] (lists back to back), or -- seg_offsets given -- at the cluster's own segment of the
+    // member-list array (the bucket path: `lists` is that array)
     __shared__ uint32_t wave_cnt[WG / 64];
     __shared__ uint32_t run[EARLY_MAX];
     const int np = min(*pred_n, EARLY_MAX);
     if (np <= 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x < EARLY_MAX) run[threadIdx.x] = eoff[threadIdx.x] + blockbase[(size_t)threadIdx.x * nblk + blockIdx.x];
+    if (threadIdx.x < np)
+        run[threadIdx.x] = (seg_offsets ? seg_offsets[pred[threadIdx.x]] : eoff[threadIdx.x]) +
+                           blockbase[(size_t)threadIdx.x * nblk + blockIdx.x];
     __syncthreads();
     const long r0 = (long)blockIdx.x * EARLY_ROWS;
     for (int i0 = 0; i0 < EARLY_ROWS; i0 += WG) {        // 256 consecutive rows per round, in row order
@@ -397,6 +405,177 @@ __global__ void __launch_bounds__(WG) early_write_kernel(const long* __restrict_
             __syncthreads();
         }
     }
+}
+
+// ---- member lists without a radix sort (the bucket path) ------------------------------------------------------
+// rocPRIM's onesweep needs eight launches (histogram, two passes, their fills) whatever n is: 107 us of a 0.5 ms
+// iteration at the 262 144 rows a rank holds in an 8-GPU run, 130 us at 2 M.  With k <= 16 384 clusters a row's bucket
+// is known from its id alone: count per cluster (LDS histogram per 4096-row block), scan, scatter to the cluster's
+// segment (slots handed out by LDS atomics: any order), then one wave per cluster restores ascending row order with
+// a bitonic sort in LDS -- lists hold 30-250 rows.  Lists longer than 2048 rows never enter the scatter: their
+// members come, in order, from the ordered compaction above (now driven by the exact counts of the scan instead
+// of a prediction), on the side stream, so their add chains start after two small kernels.
+constexpr uint32_t BK_SKIP = 0xffffffffu;
+
+__global__ void __launch_bounds__(WG) bucket_count_kernel(const long* __restrict__ ids, long n, int k, int rows_per_block,
+                                                          unsigned* __restrict__ counts) {
+    extern __shared__ unsigned bk_h[];   // k + 1 bins (the last one: ids outside [0, k))
+    for (int b = threadIdx.x; b <= k; b += WG) bk_h[b] = 0;
+    __syncthreads();
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    for (int i = threadIdx.x; i < rows_per_block; i += WG) {
+        const long r = r0 + i;
+        if (r < n) {
+            const long id = ids[r];
+            atomicAdd(&bk_h[(id >= 0 && id < k) ? (int)id : k], 1u);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b <= k; b += WG)
+        if (bk_h[b]) atomicAdd(&counts[b], bk_h[b]);
+}
+
+// one workgroup: offsets (exclusive scan of the k+1 counts, offsets[k+1] = n), cursor = offsets (BK_SKIP for the
+// clusters the compaction serves), longs[0] = number of long clusters, longs[1..] = their ids in ascending order
+// (the first EARLY_MAX are the compaction's); counts are zeroed for the next call.
+__global__ void __launch_bounds__(1024) bucket_scan_kernel(unsigned* __restrict__ counts, int k, uint32_t long_list,
+                                                           uint32_t* __restrict__ offsets, unsigned* __restrict__ cursor,
+                                                           int* __restrict__ longs) {
+    __shared__ uint32_t part[1024], lpart[1024];
+    const int t = threadIdx.x;
+    const int per = (k + 1 + 1023) / 1024;
+    const int lo = min(k + 1, t * per), hi = min(k + 1, lo + per);
+    uint32_t s = 0, nl = 0;
+    for (int b = lo; b < hi; b++) {
+        const uint32_t c = counts[b];
+        s += c;
+        nl += (b < k && c > long_list) ? 1u : 0u;
+    }
+    part[t] = s;
+    lpart[t] = nl;
+    __syncthreads();
+    if (t < 64) {   // exclusive scans of the 1024 partial sums: 16 per lane, then across the wave
+        uint32_t a[16], la[16], sa = 0, sl = 0;
+#pragma unroll
+        for (int u = 0; u < 16; u++) { a[u] = part[16 * t + u]; la[u] = lpart[16 * t + u]; sa += a[u]; sl += la[u]; }
+        uint32_t xa = sa, xl = sl;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t ya = __shfl_up(xa, off), yl = __shfl_up(xl, off);
+            if (t >= off) { xa += ya; xl += yl; }
+        }
+        uint32_t ra = xa - sa, rl = xl - sl;
+#pragma unroll
+        for (int u = 0; u < 16; u++) { part[16 * t + u] = ra; lpart[16 * t + u] = rl; ra += a[u]; rl += la[u]; }
+        if (t == 63) { offsets[k + 1] = xa; longs[0] = (int)xl; }
+    }
+    __syncthreads();
+    uint32_t run = part[t], lrun = lpart[t];
+    for (int b = lo; b < hi; b++) {
+        const uint32_t c = counts[b];
+        offsets[b] = run;
+        const bool is_long = b < k && c > long_list;
+        cursor[b] = (is_long && lrun < (uint32_t)EARLY_MAX) ? BK_SKIP : run;
+        if (is_long) longs[1 + lrun++] = b;
+        run += c;
+        counts[b] = 0;
+    }
+}
+
+__global__ void __launch_bounds__(WG) bucket_scatter_kernel(const long* __restrict__ ids, long n, int k, int rows_per_block,
+                                                            unsigned* __restrict__ cursor, uint32_t* __restrict__ order) {
+    extern __shared__ unsigned bk_s[];   // cnt[k+1] | base[k+1]
+    unsigned* cnt = bk_s;
+    unsigned* base = bk_s + (k + 1);
+    for (int b = threadIdx.x; b <= k; b += WG) cnt[b] = 0;
+    __syncthreads();
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    for (int i = threadIdx.x; i < rows_per_block; i += WG) {
+        const long r = r0 + i;
+        if (r < n) {
+            const long id = ids[r];
+            atomicAdd(&cnt[(id >= 0 && id < k) ? (int)id : k], 1u);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b <= k; b += WG) {
+        const unsigned c = cnt[b];
+        if (c) base[b] = cursor[b] == BK_SKIP ? BK_SKIP : atomicAdd(&cursor[b], c);
+        cnt[b] = 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows_per_block; i += WG) {
+        const long r = r0 + i;
+        if (r < n) {
+            const long id = ids[r];
+            const int b = (id >= 0 && id < k) ? (int)id : k;
+            const unsigned bs = base[b];
+            if (bs != BK_SKIP) order[bs + atomicAdd(&cnt[b], 1u)] = (uint32_t)r;
+        }
+    }
+}
+
+// one wave per cluster: its 2 .. 2048 members into ascending row order (bitonic sort in LDS, padded with ~0)
+__global__ void __launch_bounds__(WG) member_sort_kernel(uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
+                                                         int k, uint32_t long_list) {
+    __shared__ uint32_t ms[WG / 64][2048];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * (WG / 64) + wave;
+    if (c > k) return;   // (c == k: the trailing bucket of ids outside [0, k); sorted too when it fits)
+    const uint32_t beg = offsets[c], len = offsets[c + 1] - beg;
+    if (len < 2 || len > long_list || len > 2048u) return;
+    uint32_t P = 2;
+    while (P < len) P <<= 1;
+    uint32_t* s = ms[wave];
+    for (uint32_t i = lane; i < P; i += 64) s[i] = i < len ? order[beg + i] : 0xffffffffu;
+    for (uint32_t size = 2; size <= P; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            __builtin_amdgcn_wave_barrier();   // (a wave's LDS operations execute in order; this keeps the compiler from moving them)
+            for (uint32_t i = lane; i < P / 2; i += 64) {
+                const uint32_t pos = 2 * i - (i & (stride - 1));
+                const uint32_t a = s[pos], b = s[pos + stride];
+                const bool up = (pos & size) == 0;
+                if ((a > b) == up) { s[pos] = b; s[pos + stride] = a; }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < len; i += 64) order[beg + i] = s[i];
+}
+
+// the few long clusters beyond the compaction's EARLY_MAX: rank sort of the scattered segment by one workgroup
+// (rows are distinct: rank = number of smaller rows), through a scratch copy
+__global__ void __launch_bounds__(1024) long_ranksort_kernel(uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
+                                                             const int* __restrict__ longs, uint32_t* __restrict__ scratch) {
+    __shared__ uint32_t tile[1024];
+    const int nl = longs[0];
+    for (int slot = EARLY_MAX + blockIdx.x; slot < nl; slot += gridDim.x) {
+        const int c = longs[1 + slot];
+        const uint32_t beg = offsets[c], len = offsets[c + 1] - beg;
+        for (uint32_t i0 = 0; i0 < len; i0 += 1024) {
+            const uint32_t i = i0 + threadIdx.x;
+            const uint32_t mine = i < len ? order[beg + i] : 0u;
+            uint32_t rank = 0;
+            for (uint32_t j0 = 0; j0 < len; j0 += 1024) {
+                __syncthreads();
+                tile[threadIdx.x] = j0 + threadIdx.x < len ? order[beg + j0 + threadIdx.x] : 0xffffffffu;
+                __syncthreads();
+                const uint32_t m = min(1024u, len - j0);
+                for (uint32_t j = 0; j < m; j++) rank += tile[j] < mine;
+            }
+            if (i < len) scratch[beg + rank] = mine;
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < len; i += 1024) order[beg + i] = scratch[beg + i];
+        __syncthreads();
+    }
+}
+
+// sorted_ids[p] = the cluster of position p (k for the trailing bucket of invalid ids)
+__global__ void __launch_bounds__(WG) segment_ids_kernel(const uint32_t* __restrict__ offsets, int k, uint32_t* __restrict__ sorted_ids) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (WG / 64) + (threadIdx.x >> 6);
+    if (c > k) return;
+    for (uint32_t p = offsets[c] + lane; p < offsets[c + 1]; p += 64) sorted_ids[p] = (uint32_t)c;
 }
 
 __global__ void __launch_bounds__(WG) centroid_finalize_kernel(const float* __restrict__ sums_parts,
@@ -490,6 +669,122 @@ __global__ void __launch_bounds__(WG) histogram_kernel(const long* __restrict__ 
     }
 }
 
+// at_centroid_accum_f32 by the bucket path (k <= 16 384): see the kernels above.
+int accum_buckets(at_ctx* ctx, const float* x, int64_t n, int d, const int64_t* ids, int k, float* sums, float* counts,
+                  uint32_t* order_out, uint32_t* sorted_ids_out, hipStream_t stream) {
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    const int nblk = (int)((n + EARLY_ROWS - 1) / EARLY_ROWS);
+    uint32_t* order = static_cast<uint32_t*>(at_ws(ctx, WS_SORT_VALS_A, nn * 4, stream));
+    uint32_t* offsets = static_cast<uint32_t*>(at_ws(ctx, WS_SEG_OFFSETS, ((size_t)k + 2) * 4, stream));
+    // counts[k+1] (zero between calls: the scan clears what it has read) | cursor[k+1] | longs[k+2]
+    const bool fresh = ctx->ws_bytes[WS_BUCKETS] < ((size_t)3 * k + 8) * 4;
+    unsigned* bw = static_cast<unsigned*>(at_ws(ctx, WS_BUCKETS, ((size_t)3 * k + 8) * 4, stream));
+    uint32_t* ew = static_cast<uint32_t*>(at_ws(ctx, WS_LONG_EARLY, ((size_t)2 * EARLY_MAX * nblk + EARLY_MAX + 1 + nn) * 4, stream));
+    if (!order || !offsets || !bw || !ew) return AT_E_NOMEM;
+    if (fresh || ctx->buckets_k != k) {
+        AT_HIP(hipMemsetAsync(bw, 0, ((size_t)3 * k + 8) * 4, stream));
+        ctx->buckets_k = k;
+    }
+    unsigned* bcounts = bw;
+    unsigned* cursor = bw + (k + 1);
+    int* longs = reinterpret_cast<int*>(bw + 2 * (k + 1));
+    uint32_t* blockcnt = ew;
+    uint32_t* blockbase = ew + (size_t)EARLY_MAX * nblk;
+    uint32_t* scratch = blockbase + (size_t)EARLY_MAX * nblk + EARLY_MAX + 1;
+
+    const bool al = at_aligned16(x);
+    const bool long_ok = d % 4 == 0 && al;
+    const uint32_t long_list = long_ok ? 2048u : UINT32_MAX;   // (without the sliced kernel every list is a short one)
+    const size_t lds1 = ((size_t)k + 1) * 4, lds3 = 2 * lds1;
+    static size_t attr1 = 0, attr3 = 0;
+    if (lds1 > 48 * 1024 && lds1 > attr1) {
+        AT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        attr1 = lds1;
+    }
+    if (lds3 > 48 * 1024 && lds3 > attr3) {
+        AT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+        attr3 = lds3;
+    }
+    const long* idl = reinterpret_cast<const long*>(ids);
+    // rows per workgroup of the count / scatter passes: enough workgroups to fill the chip at small n (each pays
+    // three passes over the k bins), 4096 rows at large n
+    int rpb = (int)(n / 1024);
+    rpb = rpb < 512 ? 512 : (rpb > 4096 ? 4096 : rpb);
+    rpb = (rpb + WG - 1) / WG * WG;
+    const int nbk = (int)((n + rpb - 1) / rpb);
+    if (n > 0) {
+        hipLaunchKernelGGL(bucket_count_kernel, dim3(nbk), dim3(WG), lds1, stream, idl, (long)n, k, rpb, bcounts);
+        AT_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, bcounts, k, long_list, offsets, cursor, longs);
+    AT_LAUNCH_CHECK();
+    const bool have_long = long_ok && n > (int64_t)long_list;
+    if (have_long) {
+        if (!ctx->side_stream) {
+            AT_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+            AT_HIP(hipEventCreateWithFlags(&ctx->side_ev[0], hipEventDisableTiming));
+            AT_HIP(hipEventCreateWithFlags(&ctx->side_ev[1], hipEventDisableTiming));
+        }
+        // side stream: the long clusters' members by ordered compaction straight into their segments, then their sums
+        hipStream_t ss = ctx->side_stream;
+        AT_HIP(hipEventRecord(ctx->side_ev[0], stream));          // offsets / longs are ready
+        AT_HIP(hipStreamWaitEvent(ss, ctx->side_ev[0], 0));
+        hipLaunchKernelGGL(early_count_kernel, dim3(nblk), dim3(WG), 0, ss, idl, (long)n, longs + 1, longs, nblk, blockcnt);
+        hipLaunchKernelGGL(early_scan_kernel, dim3(1), dim3(1024), 0, ss, blockcnt, nblk, blockbase, blockbase + (size_t)EARLY_MAX * nblk);
+        hipLaunchKernelGGL(early_write_kernel, dim3(nblk), dim3(WG), 0, ss, idl, (long)n, longs + 1, longs, nblk, blockbase,
+                           nullptr, order, offsets);
+        hipLaunchKernelGGL(centroid_accum_long_kernel, dim3(EARLY_MAX, d / 4), dim3(WG), 0, ss, x, d, order, offsets, long_list,
+                           sums, counts, k, 0, longs, nullptr, nullptr, 0u, 0, EARLY_MAX);
+        AT_LAUNCH_CHECK();
+    }
+    if (n > 0) {
+        hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nbk), dim3(WG), lds3, stream, idl, (long)n, k, rpb, cursor, order);
+        hipLaunchKernelGGL(member_sort_kernel, dim3((k + 1 + WG / 64 - 1) / (WG / 64)), dim3(WG), 0, stream, order, offsets, k, 2048u);
+        AT_LAUNCH_CHECK();
+    }
+    if (have_long) {
+        // more than EARLY_MAX long clusters (rare): the rest were scattered; rank-sort them, then their sums
+        hipStream_t ss = ctx->side_stream;
+        AT_HIP(hipEventRecord(ctx->side_ev[0], stream));          // scattered segments are ready
+        AT_HIP(hipStreamWaitEvent(ss, ctx->side_ev[0], 0));
+        hipLaunchKernelGGL(long_ranksort_kernel, dim3(16), dim3(1024), 0, ss, order, offsets, longs, scratch);
+        hipLaunchKernelGGL(centroid_accum_long_kernel, dim3(16, d / 4), dim3(WG), 0, ss, x, d, order, offsets, long_list,
+                           sums, counts, k, 0, longs, nullptr, nullptr, 0u, EARLY_MAX, 0x7fffffff);
+        AT_LAUNCH_CHECK();
+        AT_HIP(hipEventRecord(ctx->side_ev[1], ss));
+    }
+    int vec = 1;
+    if (d % 4 == 0 && d >= 256 && al) vec = 4;
+    else if (d % 2 == 0 && d >= 128 && al) vec = 2;
+    const int slabs = (d + 64 * vec - 1) / (64 * vec);
+    const long waves = (long)k * slabs;
+    const dim3 grid((unsigned)((waves + WG / 64 - 1) / (WG / 64)));
+    // lists of 1025 .. 2048 rows that no local sort took (member_sort_kernel's capacity is 2048: none) -- and, when the
+    // sliced kernel cannot run (d % 4 != 0), lists of any length: those need the sorted order too
+    if (vec == 4)
+        hipLaunchKernelGGL(centroid_accum_kernel<4>, grid, dim3(WG), 0, stream, x, d, order, offsets, k, slabs, long_list, sums, counts);
+    else if (vec == 2)
+        hipLaunchKernelGGL(centroid_accum_kernel<2>, grid, dim3(WG), 0, stream, x, d, order, offsets, k, slabs, long_list, sums, counts);
+    else
+        hipLaunchKernelGGL(centroid_accum_kernel<1>, grid, dim3(WG), 0, stream, x, d, order, offsets, k, slabs, long_list, sums, counts);
+    AT_LAUNCH_CHECK();
+    if ((order_out || sorted_ids_out) && have_long) {
+        // the copies below read the long clusters' segments, which the side stream writes
+        AT_HIP(hipStreamWaitEvent(stream, ctx->side_ev[1], 0));
+    }
+    if (order_out && n > 0)
+        AT_HIP(hipMemcpyAsync(order_out, order, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+    if (sorted_ids_out && n > 0) {
+        hipLaunchKernelGGL(segment_ids_kernel, dim3((k + 1 + WG / 64 - 1) / (WG / 64)), dim3(WG), 0, stream, offsets, k, sorted_ids_out);
+        AT_LAUNCH_CHECK();
+    }
+    if (have_long) {
+        if (ctx->defer_join && !(order_out || sorted_ids_out)) ctx->join_pending = 1;
+        else AT_HIP(hipStreamWaitEvent(stream, ctx->side_ev[1], 0));
+    }
+    return AT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -524,6 +819,12 @@ int at_centroid_accum_f32(at_ctx* ctx, const float* x, int64_t n, int d, const i
                "at_centroid_accum_f32: bad sizes n=%lld d=%d k=%d", (long long)n, d, k);
     AT_REQUIRE(sums && counts && (n == 0 || (x && ids)), "at_centroid_accum_f32: null pointer");
     AT_HIP(hipSetDevice(ctx->device));
+    // The bucket path pays off where the radix sort's eight launches are fixed cost: few rows per cluster (the
+    // per-rank share of a sharded run).  At 2 M rows its scattered 4-byte stores (134 us) and the in-LDS order of 1000+
+    // row lists (159 us) lose to two onesweep passes.  (It hands lists longer than 2048 rows to the feature-sliced
+    // kernel: that needs d % 4 == 0.)
+    if (ctx->dbg.accum_buckets != 0 && k <= 16384 && n <= 64 * (int64_t)k && d % 4 == 0 && at_aligned16(x))
+        return accum_buckets(ctx, x, n, d, ids, k, sums, counts, order_out, sorted_ids_out, stream);
 
     const size_t nn = (size_t)(n > 0 ? n : 1);
     uint32_t* keys_a = static_cast<uint32_t*>(at_ws(ctx, WS_SORT_KEYS_A, nn * 4, stream));
@@ -563,9 +864,9 @@ int at_centroid_accum_f32(at_ctx* ctx, const float* x, int64_t n, int d, const i
                            nblk, blockcnt);
         hipLaunchKernelGGL(early_scan_kernel, dim3(1), dim3(1024), 0, ss, blockcnt, nblk, blockbase, eoff);
         hipLaunchKernelGGL(early_write_kernel, dim3(nblk), dim3(WG), 0, ss, reinterpret_cast<const long*>(ids), (long)n, pw + 1, pw,
-                           nblk, blockbase, eoff, lists);
+                           nblk, blockbase, eoff, lists, nullptr);
         hipLaunchKernelGGL(centroid_accum_long_kernel, dim3(EARLY_MAX, d / 4), dim3(WG), 0, ss, x, d, lists, eoff, 2048u, sums,
-                           counts, k, 1, pw + 1, pw, reinterpret_cast<unsigned*>(pw + 16), gen);
+                           counts, k, 1, pw + 1, pw, reinterpret_cast<unsigned*>(pw + 16), gen, 0, 0x7fffffff);
         AT_LAUNCH_CHECK();
         // the regular pass rebuilds the prediction: its counter starts from zero once the early pass has read it
         AT_HIP(hipMemsetAsync(pw, 0, 4, ss));
@@ -628,7 +929,7 @@ int at_centroid_accum_f32(at_ctx* ctx, const float* x, int64_t n, int d, const i
         hipLaunchKernelGGL(long_detect_kernel, dim3((k + WG - 1) / WG), dim3(WG), 0, ctx->side_stream, offsets, k, long_list,
                            done, gen, pred, pred_n, late);
         hipLaunchKernelGGL(centroid_accum_long_kernel, dim3(32, d / 4), dim3(WG), 0, ctx->side_stream, x, d, order,
-                           offsets, long_list, sums, counts, k, 0, late, nullptr, done, gen);
+                           offsets, long_list, sums, counts, k, 0, late, nullptr, done, gen, 0, 0x7fffffff);
         AT_LAUNCH_CHECK();
         AT_HIP(hipEventRecord(ctx->side_ev[1], ctx->side_stream));
     }

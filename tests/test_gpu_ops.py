@@ -306,6 +306,44 @@ def test_centroid_accum_is_the_sequential_sum(be, n, d, k):
     assert np.array_equal(h.cpu().numpy(), counts)
 
 
+@pytest.mark.parametrize("buckets", [1, 0])
+@pytest.mark.parametrize("n,d,k,n_long", [(300000, 64, 5000, 3), (400000, 64, 6400, 24), (120000, 128, 2000, 1), (90000, 8, 1500, 2),
+                                          (50000, 6, 40, 2), (300000, 64, 500, 3)])
+def test_centroid_accum_long_lists_both_paths(be, switches, buckets, n, d, k, n_long):
+    """Member lists by the bucket path (count / scan / scatter / in-LDS order; long lists by ordered compaction, more
+    than sixteen of them through the rank-sort fallback) and by the radix sort: the sequential sums, the counts, the
+    (id, row) order and the ids in that order, bit for bit -- including ids outside [0, k)."""
+    switches(accum_buckets=buckets)
+    rng = np.random.default_rng(n + k + n_long)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    ids = rng.integers(0, k, n)
+    heavy = rng.choice(k, n_long, replace=False)
+    pick = rng.random(n) < 0.7
+    ids[pick] = heavy[rng.integers(0, n_long, int(pick.sum()))]      # 70 % of the rows in the heavy clusters
+    ids[rng.integers(0, n, 50)] = -1                                  # ids outside [0, k): a trailing bucket nobody sums
+    ids[rng.integers(0, n, 50)] = k + 7
+    xt = be._f32(x)
+    idt = torch.from_numpy(ids).to(be.device)
+    for _ in range(2):                                                # (twice: the scan leaves the counters clean)
+        part, (order, sorted_ids) = be.centroid_accum(xt, idt, k, want_order=True)
+    valid = (ids >= 0) & (ids < k)
+    key = np.where(valid, ids, k)
+    ref_order = np.argsort(key, kind="stable")
+    nv = int(valid.sum())
+    got_order = order.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got_order[:nv], ref_order[:nv].astype(np.uint32))
+    assert np.array_equal(np.sort(got_order[nv:]), np.sort(ref_order[nv:]).astype(np.uint32))
+    assert np.array_equal(sorted_ids.cpu().numpy().view(np.uint32), key[ref_order].astype(np.uint32))
+    sums = np.zeros((k, d), np.float32)
+    np.add.at(sums, ids[valid], x[valid])                             # unbuffered, ascending row: the sequential fp32 sum
+    counts = np.bincount(ids[valid], minlength=k).astype(np.float32)
+    p = part.cpu().numpy()
+    assert np.array_equal(bits(p[: k * d].reshape(k, d)), bits(sums))
+    assert np.array_equal(p[k * d: k * d + k], counts)
+    assert int((counts > 2048).sum()) >= min(n_long, 1)
+    assert (buckets == 0) or (n > 64 * k) or (d % 4) or int((counts > 2048).sum()) == n_long
+
+
 def test_sum_and_nonfinite(be):
     rng = np.random.default_rng(1)
     v = rng.random(1_000_003).astype(np.float32)
