@@ -50,6 +50,7 @@ enum at_ws_slot {
     WS_LONG_EARLY,     // centroid_accum: block counts / bases and the member lists of the early set
     WS_LONG_LATE,      // centroid_accum: long clusters left to the pass behind the sort
     WS_BUCKETS,        // centroid_accum bucket path: counts, cursors, the list of long clusters
+    WS_LOGMEL_ANY,     // log-mel, general n_fft: window, twiddles, banded filterbank
     WS_NSLOTS
 };
 
@@ -92,6 +93,8 @@ struct at_ctx {
     hipEvent_t mt_ready;   // behind the generation of WS_MT_RAW
     int mt_have;
     uint32_t mt_seed;
+    int any_sr, any_nfft, any_nmels;   // what WS_LOGMEL_ANY holds
+    float* any_user_copy;
     float* fb_user_copy;   // host copy of the user filterbank the tables were built from (malloc'd; compared per call)
     int n_cus;             // multiProcessorCount of the device (read once in at_create)
     int rs_orig, rs_new;  // what WS_RESAMPLE_TAPS currently holds
@@ -170,6 +173,11 @@ int at_filter_gather_ambiguous(at_ctx* ctx, uint32_t* amb_list, uint32_t* amb_so
 int at_filter_redo_rows(at_ctx* ctx, const float* x, int d, const float* c, int k, const uint32_t* list, int64_t m,
                         const uint32_t* order, const int32_t* cperm, const float* dmin, int ng, const unsigned* misc,
                         const uint32_t* aux, int64_t* ids, float* dist, const unsigned* count_dev, hipStream_t stream);
+
+// logmel_any.hip: every power-of-two n_fft other than 512
+int at_logmel_any(at_ctx* ctx, const float* wave, int64_t n_clips, int64_t L, int64_t wave_stride, int sample_rate,
+                  int n_fft, int hop, int n_mels, const float* fb_user_dev, float* out, int frame_major,
+                  hipStream_t stream);
 
 int at_group_min_dist_f16(at_ctx* ctx, const float* c, int k, int d, const int32_t* cperm, int ng, float* dmin,
                           hipStream_t stream);

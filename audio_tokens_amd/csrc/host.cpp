@@ -115,6 +115,7 @@ void at_destroy(at_ctx* ctx) {
     if (ctx->mt_ready) (void)hipEventDestroy(ctx->mt_ready);
     if (ctx->filter_host_misc) (void)hipHostFree(ctx->filter_host_misc);
     std::free(ctx->fb_user_copy);
+    std::free(ctx->any_user_copy);
     (void)hipSetDevice(prev);
     delete ctx;
 }
@@ -157,6 +158,7 @@ void* at_ws(at_ctx* ctx, int slot, size_t bytes, hipStream_t stream) {
     if (slot == WS_MT_RAW) ctx->mt_have = 0;
     if (slot == WS_LONG_PRED) ctx->long_pred_k = 0;
     if (slot == WS_BUCKETS) ctx->buckets_k = 0;
+    if (slot == WS_LOGMEL_ANY) ctx->any_nfft = 0;
     return p;
 }
 

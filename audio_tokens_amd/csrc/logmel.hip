@@ -345,17 +345,26 @@ extern "C" int at_logmel_f32(at_ctx* ctx, const float* wave, int64_t n_clips, in
                              void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     AT_REQUIRE(ctx, "at_logmel_f32: ctx is null");
-    AT_REQUIRE(n_fft == NFFT, "at_logmel_f32: n_fft=%d not supported (this version: 512)", n_fft);
-    AT_REQUIRE(hop >= 1 && hop <= NFFT, "at_logmel_f32: hop=%d out of range [1, %d]", hop, NFFT);
+    AT_REQUIRE(n_fft >= 64 && n_fft <= 4096 && (n_fft & (n_fft - 1)) == 0,
+               "at_logmel_f32: n_fft=%d not supported (a power of two from 64 to 4096)", n_fft);
+    AT_REQUIRE(hop >= 1 && hop <= n_fft, "at_logmel_f32: hop=%d out of range [1, %d]", hop, n_fft);
     AT_REQUIRE(n_mels >= 1 && n_mels <= 1024, "at_logmel_f32: n_mels=%d out of range", n_mels);
     AT_REQUIRE(n_clips >= 0 && n_clips <= 65535 * 1024L, "at_logmel_f32: n_clips out of range");
-    AT_REQUIRE(L > NFFT / 2, "at_logmel_f32: clip length %lld must exceed n_fft/2 (reflect padding)", (long long)L);
+    AT_REQUIRE(L > n_fft / 2, "at_logmel_f32: clip length %lld must exceed n_fft/2 (reflect padding)", (long long)L);
     AT_REQUIRE(wave_stride >= L, "at_logmel_f32: wave_stride < L");
     AT_REQUIRE(layout == AT_LAYOUT_MEL_MAJOR || layout == AT_LAYOUT_FRAME_MAJOR, "at_logmel_f32: bad layout");
     AT_REQUIRE(!fuse_l2norm || layout == AT_LAYOUT_FRAME_MAJOR, "at_logmel_f32: fuse_l2norm needs the frame-major layout");
     if (n_clips == 0) return AT_OK;
     AT_REQUIRE(wave && out, "at_logmel_f32: null pointer");
     AT_HIP(hipSetDevice(ctx->device));
+    if (n_fft != NFFT) {   // the general form (logmel_any.hip); unit rows by the stand-alone kernel behind it
+        AT_REQUIRE(at_num_frames(L, hop) < (1LL << 31), "at_logmel_f32: too many frames per clip");
+        int rc = at_logmel_any(ctx, wave, n_clips, L, wave_stride, sample_rate, n_fft, hop, n_mels, fb_or_null, out,
+                               layout == AT_LAYOUT_FRAME_MAJOR, stream);
+        if (rc) return rc;
+        if (fuse_l2norm) return at_l2norm_rows_f32(ctx, out, n_clips * at_num_frames(L, hop), n_mels, out, stream_);
+        return AT_OK;
+    }
 
     LogmelParams p;
     int rc = build_tables(ctx, sample_rate, n_mels, hop, fb_or_null, stream, &p.tabs, &p.fb_start, &p.fb_len,

@@ -87,7 +87,8 @@ int at_split_clusters_host(int d, int k, int64_t n, float* hassign_host, float* 
 /* Fused STFT -> |.|^2 -> mel -> 10*log10(max(.,1e-10)).
  *   wave: n_clips clips of L samples, clip i at wave + i*wave_stride (floats).
  *   fb_or_null: DEVICE [n_fft/2+1][n_mels] filterbank, or NULL = the library's own
- *   (at_mel_filterbank_host values).  n_fft must be 512 in this version; hop divides n_fft.
+ *   (at_mel_filterbank_host values).  n_fft: a power of two from 64 to 4096 (512, the reference's default, takes
+ *   the tuned kernel; the others a general radix-2 form); 1 <= hop <= n_fft.
  *   out: n_clips*n_mels*T floats in `layout`.  fuse_l2norm != 0 (frame-major only) additionally
  *   applies at_l2norm_rows_f32 to every frame before it is stored. */
 int at_logmel_f32(at_ctx* ctx, const float* wave, int64_t n_clips, int64_t L, int64_t wave_stride,

@@ -412,6 +412,34 @@ def test_logmel_other_hops_and_widths(be, oracle, hop, n_mels):
     assert np.array_equal(bits(fmn), bits(ref_n))
 
 
+@pytest.mark.parametrize("n_fft,hop,n_mels", [(1024, 512, 64), (1024, 256, 128), (256, 64, 40), (2048, 512, 64), (64, 16, 8),
+                                              (4096, 1024, 128)])
+def test_logmel_other_nfft(be, oracle, n_fft, hop, n_mels):
+    """n_fft is a configuration knob of the reference (audio_tokens_config.py:39; its README documents 1024 / 512):
+    every power of two other than the tuned 512 goes through the general radix-2 kernel -- same tolerance against
+    the oracle, both layouts, unit rows, a user filterbank, silence exactly -100 dB."""
+    rng = np.random.default_rng(n_fft + hop)
+    L = 30001
+    clips = (0.1 * rng.standard_normal((4, L))).astype(np.float32)
+    clips[1] = (0.3 * np.sin(2 * np.pi * 1234.5 * np.arange(L) / 22050)).astype(np.float32)
+    clips[3, 4000:] = 0.0
+    ref = np.stack([oracle.logmel(c, n_fft=n_fft, hop=hop, n_mels=n_mels) for c in clips])
+    got = be.logmel(clips, 22050, n_fft, hop, n_mels).cpu().numpy()
+    assert got.shape == ref.shape == (4, n_mels, 1 + L // hop)
+    ok = _logmel_tolerance(got, ref)
+    assert ok.all(), f"{(~ok).sum()} of {ok.size} bins outside tolerance"
+    assert (got[3, :, -3:] == -100.0).all()
+    fm = be.logmel(clips, 22050, n_fft, hop, n_mels, frame_major=True).cpu().numpy()
+    assert np.array_equal(fm.reshape(4, -1, n_mels), got.transpose(0, 2, 1))
+    fmn = be.logmel(clips, 22050, n_fft, hop, n_mels, frame_major=True, l2norm=True).cpu().numpy()
+    assert np.array_equal(bits(fmn), bits(fm / (np.linalg.norm(fm, axis=1, keepdims=True) + 1e-10)))
+    fb = oracle.mel_filterbank(22050, n_fft, n_mels)[:, ::-1].copy()          # a user filterbank: mel axis reversed
+    rev = be.logmel(clips, 22050, n_fft, hop, n_mels, fb=fb).cpu().numpy()
+    assert _logmel_tolerance(rev[:, ::-1], ref).all()
+    again = be.logmel(clips, 22050, n_fft, hop, n_mels).cpu().numpy()          # and back to the library's own
+    assert np.array_equal(bits(again), bits(got))
+
+
 def test_logmel_full_length_clip_shapes(be, oracle):
     rng = np.random.default_rng(4)
     w = (0.1 * rng.standard_normal((3, 220500))).astype(np.float32)

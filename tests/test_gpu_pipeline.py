@@ -275,3 +275,19 @@ def test_normalize_option_is_one_kernel_with_torchs_bits(workdir, be):
         ref = SpectrogramGenerator.normalize_spectrogram(a["spec"])
         assert torch.equal(b["spec"].view(torch.int32), ref.view(torch.int32))
         assert float(b["spec"].min()) == 0.0 and float(b["spec"].max()) == 1.0
+
+
+def test_generator_with_the_readme_hyperparameters(workdir, oracle):
+    """n_fft = 1024 / hop_length = 512 (the values the reference's README documents) through SpectrogramGenerator."""
+    import dataclasses
+    from audio_tokens_amd.processors import SpectrogramGenerator
+    cfg, split, waves = workdir
+    cfg = dataclasses.replace(cfg, n_fft=1024, hop_length=512)
+    specs = SpectrogramGenerator(cfg).populate_specs(split["train"][:3])
+    assert len(specs) == 3
+    for sp in specs:
+        y = sp["filename"][:-4]
+        ref = oracle.logmel(waves[y], n_fft=1024, hop=512)
+        assert tuple(sp["spec"].shape) == ref.shape == (64, 1 + 44100 // 512)
+        P, Pr = 10.0 ** (sp["spec"].double().numpy() / 10), 10.0 ** (ref.astype(np.float64) / 10)
+        assert (np.abs(P - Pr) <= 2e-5 * Pr + 1e-9 * Pr.max(0, keepdims=True) + 1e-14).all()
