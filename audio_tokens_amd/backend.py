@@ -578,15 +578,31 @@ class HipBackend(HostHelpers):
             _lib.check(self.lib.at_split_clusters_f32(self.ctx.handle, d, k, n, _ptr(hassign), _ptr(cent), _ptr(nsplit_out),
                                                       self._stream()))
 
-    def lloyd_stats(self, hassign, parts, k: int, d: int, stats_row) -> None:
-        """stats_row (float64 [2]) <- (objective summed over the packed partials in rank order, imbalance)."""
-        if parts.dim() == 1:
-            parts = parts.unsqueeze(0)
-        off, total = self.part_layout(k, d)
-        assert parts.is_contiguous() and parts.shape[1] == total and stats_row.dtype == torch.float64
+    def lloyd_stats(self, hassign, parts, k: int, d: int, stats_row, objs=None) -> None:
+        """stats_row (float64 [2]) <- (objective summed in rank order, imbalance).  The per-rank objectives are the
+        doubles riding at the end of the packed partials, or -- objs given -- a float64 tensor [n_ranks]."""
+        assert stats_row.dtype == torch.float64
+        if objs is not None:
+            assert objs.dtype == torch.float64 and objs.is_contiguous()
+            ptr, stride, n_parts = _ptr(objs), 1, objs.numel()
+        else:
+            if parts.dim() == 1:
+                parts = parts.unsqueeze(0)
+            off, total = self.part_layout(k, d)
+            assert parts.is_contiguous() and parts.shape[1] == total
+            ptr, stride, n_parts = _vp(parts.data_ptr() + 4 * off), total // 2, parts.shape[0]
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.at_lloyd_stats_f64(self.ctx.handle, _ptr(hassign), k, _vp(parts.data_ptr() + 4 * off),
-                                                   total // 2, parts.shape[0], _ptr(stats_row), self._stream()))
+            _lib.check(self.lib.at_lloyd_stats_f64(self.ctx.handle, _ptr(hassign), k, ptr, stride, n_parts, _ptr(stats_row),
+                                                   self._stream()))
+
+    def sum_parts(self, parts) -> torch.Tensor:
+        """parts [n_parts, m] float32 -> [m]: added in ascending part order (at_sum_parts_f32)."""
+        assert parts.dim() == 2 and parts.is_contiguous() and parts.dtype == torch.float32
+        out = self.empty((parts.shape[1],))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_sum_parts_f32(self.ctx.handle, _ptr(parts), parts.stride(0), parts.shape[0], parts.shape[1],
+                                                 _ptr(out), self._stream()))
+        return out
 
     def to_host_async(self, t: torch.Tensor):
         """-> (pinned host tensor, event): the copy is queued on the current stream, the caller's thread goes on;

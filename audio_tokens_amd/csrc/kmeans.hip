@@ -602,6 +602,16 @@ __global__ void __launch_bounds__(WG) centroid_finalize_kernel(const float* __re
     if (e == (long)c * d) hassign[c] = cnt;
 }
 
+// out[i] = ((parts[0][i] + parts[1][i]) + parts[2][i]) + ...: the rank-ordered sum of the scatter form of the exchange
+__global__ void __launch_bounds__(WG) sum_parts_kernel(const float* __restrict__ parts, long stride, int n_parts, long m,
+                                                       float* __restrict__ out) {
+    const long i = (long)blockIdx.x * WG + threadIdx.x;
+    if (i >= m) return;
+    float tot = 0.0f;
+    for (int p = 0; p < n_parts; p++) tot += parts[p * stride + i];
+    out[i] = tot;
+}
+
 // ---- fixed-tree reductions ---------------------------------------------------------------------
 constexpr int RED_BLOCKS = 1024;
 
@@ -971,6 +981,17 @@ int at_centroid_finalize_f32(at_ctx* ctx, const float* sums_parts, int64_t sums_
     hipLaunchKernelGGL(centroid_finalize_kernel, dim3((unsigned)((total + WG - 1) / WG)), dim3(WG), 0,
                        stream, sums_parts, (long)sums_part_stride, counts_parts,
                        (long)counts_part_stride, n_parts, k, d, centroids, hassign);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}
+
+int at_sum_parts_f32(at_ctx* ctx, const float* parts, int64_t part_stride, int n_parts, int64_t m, float* out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AT_REQUIRE(ctx && n_parts >= 1 && m >= 0 && (m == 0 || (parts && out)), "at_sum_parts_f32: bad arguments");
+    if (m == 0) return AT_OK;
+    AT_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((m + WG - 1) / WG)), dim3(WG), 0, stream, parts, (long)part_stride,
+                       n_parts, (long)m, out);
     AT_LAUNCH_CHECK();
     return AT_OK;
 }

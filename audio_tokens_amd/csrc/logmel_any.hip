@@ -6,7 +6,7 @@
 // This file is the general form: one wavefront per frame, the n_fft/2-point complex FFT of z[m] = x[2m] + i x[2m+1]
 // as radix-2 decimation-in-time stages in LDS (bit-reversed load, natural output), the same even/odd untangling to
 // the n_fft/2 + 1 power bins, the banded mel dot products, 10 log10.  Same arithmetic contract as the tuned kernel
-// (fp32 throughout, |X|^2 as re^2 + im^2, clamp at 1e-10), same tolerance against the oracle
+// (fp32 throughout, |X|^2 as re^2 + im^2, clamp at 1e-10), same tolerance against the CPU restatement
 // (tests/test_gpu_ops.py::test_logmel_other_nfft); roughly a quarter of its speed, which is the price of a
 // configuration the reference's defaults do not use.
 #include <cmath>

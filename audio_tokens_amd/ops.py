@@ -151,6 +151,34 @@ class _Dist:
             return part.unsqueeze(0)
         return self._all_gather(part).view(self.world, part.numel())
 
+    def reduce_in_rank_order(self, be, v):
+        """v [m] float32 -> the sum over the ranks of v, added in ascending rank order, identical on every rank:
+        all-to-all of the ranks' slices, ordered local sum of the slice this rank owns (at_sum_parts_f32), all-gather
+        of the reduced slices.  Moves 2 (N-1)/N m floats per rank where the all-gather of whole partials moves
+        (N-1) m -- the form for large tables (BASELINE.json's configs[4]: 8.45 MB per partial)."""
+        if not self.on:
+            return v
+        w, m = self.world, v.numel()
+        chunk = -(-m // w)
+        chunk = (chunk + 3) // 4 * 4
+        host = self.host_staged and v.device.type != "cpu"
+        src = torch.zeros(w * chunk, dtype=v.dtype, device="cpu" if host else v.device)
+        src[:m] = v.cpu() if host else v
+        recv = torch.empty_like(src)
+        self.dist.all_to_all_single(recv, src, group=self.group)          # recv[r] = rank r's copy of MY slice
+        mine = be.sum_parts((recv.to(v.device) if host else recv).view(w, chunk))
+        mine = mine.cpu() if host else mine
+        out = torch.empty(w * chunk, dtype=v.dtype, device=mine.device)
+        self.dist.all_gather_into_tensor(out, mine, group=self.group)
+        out = out.to(v.device) if host else out
+        return out[:m]
+
+    def all_gather_f64(self, v):
+        """v float64 [1] -> [world] in rank order."""
+        if not self.on:
+            return v.reshape(1)
+        return self._all_gather(v.reshape(-1))
+
     def sum_bits(self, rows):
         """Exact merge of float32 rows of which exactly one rank holds a non-zero copy."""
         if not self.on:
@@ -194,6 +222,7 @@ class Kmeans:
         self.phase_seconds = None
         self.prune = True  # exact pruning of Lloyd iterations 2..niter (d = 64 / 128 only)
         self.order_beside = True   # the visiting-order sort on a stream of its own (A/B aid)
+        self.exchange = "auto"     # "gather" | "scatter" | "auto": how the per-iteration partials are combined (see train)
 
     # ------------------------------------------------------------------------------------
     def train(self, x, init_centroids=None, sync=True, check_finite=True):
@@ -273,6 +302,9 @@ class Kmeans:
         stats_dev = be.zeros((max(niter, 1), 2), torch.float64)
         nsplit_dev = be.zeros((max(niter, 1),), torch.int32)
         obj_off, part_len = be.part_layout(k, d)
+        # the exchange: an all-gather of whole partials (one collective, (N-1) x the table per rank) up to 4 MB,
+        # all-to-all + ordered local sum + all-gather (2 (N-1)/N x the table) above; both add in rank order
+        scatter_exchange = dist.on and (self.exchange == "scatter" or (self.exchange == "auto" and part_len * 4 > (4 << 20)))
         t0 = time.time()
         prof = self.phase_seconds  # None, or a dict that collects per-phase wall time (debug aid)
 
@@ -369,9 +401,19 @@ class Kmeans:
             else:
                 part, order = be.centroid_accum(xs, ids, k, out=part, want_order=True)
             tp = lap("accumulate", tp)
-            parts = dist.all_gather_parts(part)
-            cent, hassign = be.centroid_finalize(parts, k, d)
-            be.lloyd_stats(hassign, parts, k, d, stats_dev[it])
+            if scatter_exchange:
+                # (N-1)/N of the partial out, the reduced table back: sums and counts added in rank order by
+                # at_sum_parts_f32 on the slice each rank owns; the objectives travel as N doubles
+                red = be.empty((1, part_len))
+                red[0, :obj_off] = dist.reduce_in_rank_order(be, part[:obj_off])
+                red[0, obj_off:] = 0.0
+                objs = dist.all_gather_f64(part[obj_off:obj_off + 2].view(torch.float64))
+                cent, hassign = be.centroid_finalize(red, k, d)
+                be.lloyd_stats(hassign, red, k, d, stats_dev[it], objs=objs.contiguous())
+            else:
+                parts = dist.all_gather_parts(part)
+                cent, hassign = be.centroid_finalize(parts, k, d)
+                be.lloyd_stats(hassign, parts, k, d, stats_dev[it])
             be.split_clusters_device(hassign, cent, ns, nsplit_dev[it:it + 1])
             tp = lap("exchange+finalize+split", tp)
         self._last_assign = ids

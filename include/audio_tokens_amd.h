@@ -239,6 +239,12 @@ int at_centroid_finalize_f32(at_ctx* ctx, const float* sums_parts, int64_t sums_
                              const float* counts_parts, int64_t counts_part_stride, int n_parts,
                              int k, int d, float* centroids, float* hassign, void* stream);
 
+/* out[i] = parts[0][i] + parts[1][i] + ... added in ascending part order (part p at parts + p*part_stride floats, m
+ * floats each): the fixed-order reduction of the data-parallel exchange when it runs as all-to-all + local sum +
+ * all-gather instead of an all-gather of whole partials (same bits as at_centroid_finalize_f32 over all parts). */
+int at_sum_parts_f32(at_ctx* ctx, const float* parts, int64_t part_stride, int n_parts, int64_t m, float* out,
+                     void* stream);
+
 /* at_split_clusters_host on DEVICE buffers (hassign [k], centroids [k][d], both updated in place), same bits:
  * one workgroup regenerates the mt19937(1234) stream in LDS and runs the cyclic acceptance scans, so a Lloyd
  * iteration needs no host round trip to learn whether a cluster came out empty.  *nsplit_out (DEVICE int32)

@@ -87,12 +87,21 @@ class OracleBackend(HostHelpers):
         h, c = hassign.numpy(), cent.numpy()       # (views: updated in place, as the device kernel does)
         nsplit_out[0] = self.split_clusters(h, c, n) if (h == 0).any() else 0
 
-    def lloyd_stats(self, hassign, parts, k, d, stats_row):
+    def sum_parts(self, parts):
+        tot = np.zeros(parts.shape[1], np.float32)
+        for p in parts.numpy():                  # ascending rank order
+            tot = tot + p
+        return torch.from_numpy(tot)
+
+    def lloyd_stats(self, hassign, parts, k, d, stats_row, objs=None):
         off, total = self.part_layout(k, d)
-        parts = parts.reshape(-1, total)
         obj = 0.0
-        for p in parts:                          # ascending rank order
-            obj += float(p[off:off + 2].view(torch.float64)[0])
+        if objs is not None:
+            for o in objs.tolist():
+                obj += o
+        else:
+            for p in parts.reshape(-1, total):   # ascending rank order
+                obj += float(p[off:off + 2].view(torch.float64)[0])
         h = hassign.double().numpy()
         stats_row[0] = obj
         stats_row[1] = float((h * h).sum() * k / (h.sum() ** 2))

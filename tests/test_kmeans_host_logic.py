@@ -96,7 +96,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, case, q):
+def _worker(rank, world, port, case, q, exchange="auto"):
     import sys
     sys.path.insert(0, str(Path(__file__).resolve().parent))
     sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -114,23 +114,27 @@ def _worker(rank, world, port, case, q):
                 x, cut = g["a_x"], 1000
                 local = x[:cut] if rank == 0 else x[cut:]
                 km = Kmeans(64, 64, niter=20, distributed=True, backend=OracleBackend())
+                km.exchange = exchange
                 km.train(local)
             else:  # subsampled: 20000 rows, k=64 -> 16384 rows kept, spread over both ranks
                 x, cut = g["c_x"], 12345
                 local = x[:cut] if rank == 0 else x[cut:]
                 km = Kmeans(8, 64, niter=5, distributed=True, backend=OracleBackend())
+                km.exchange = exchange
                 km.train(local, init_centroids=g["c_init"])
         q.put((rank, km.centroids.copy(), [s["nsplit"] for s in km.iteration_stats], km.obj.copy()))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["plain", "subsampled"])
-def test_sharded_kmeans_gloo_world2(case, oracle):
+@pytest.mark.parametrize("case,exchange", [("plain", "auto"), ("subsampled", "auto"), ("plain", "scatter"), ("subsampled", "scatter")])
+def test_sharded_kmeans_gloo_world2(case, exchange, oracle):
+    """Both forms of the per-iteration exchange (all-gather of whole partials; all-to-all + ordered local sum +
+    all-gather) give the oracle's two-shard bits on both ranks."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, q, exchange)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
