@@ -67,6 +67,10 @@ def _worker(rank, world, port, q):
             assert kp.prune
             kp.train(xb[:14000] if rank == 0 else xb[14000:])
             out["pruned"] = kp.centroids.copy()
+            ks = Kmeans(64, 1024, niter=6, distributed=True)
+            ks.exchange = "scatter"          # all-to-all + ordered local sum + all-gather instead of the all-gather
+            ks.train(xb[:14000] if rank == 0 else xb[14000:])
+            out["pruned_scatter"] = ks.centroids.copy()
             # whole device pipeline, 2 ranks x 3 clips
             wave = synth_clips(6, L=22050 * 2, seed=11, device="cuda")
             mine = wave[rank * 3:(rank + 1) * 3]
@@ -109,6 +113,7 @@ def test_two_ranks_one_gpu(oracle, be):
         warnings.simplefilter("ignore")
         rp = oracle.kmeans_train(xb, 1024, niter=6, shard=(np.arange(30000) >= 14000).astype(np.int32), n_shards=2)
     assert np.array_equal(bits(res[0]["pruned"]), bits(rp.centroids)) and np.array_equal(bits(res[1]["pruned"]), bits(rp.centroids))
+    assert np.array_equal(bits(res[0]["pruned_scatter"]), bits(rp.centroids)) and np.array_equal(bits(res[1]["pruned_scatter"]), bits(rp.centroids))
     # pipeline: both ranks hold the same centroids; the oracle reproduces them from the same frames
     assert np.array_equal(bits(res[0]["pipe_centroids"]), bits(res[1]["pipe_centroids"]))
     from audio_tokens_amd.synth import synth_clips
