@@ -31,6 +31,10 @@ using namespace logmel;
 constexpr int WG = 256;
 constexpr int PREFETCH_REGS = 5;   // x 16 bytes x 256 lanes = 5120 samples per block: 32 frames at hop <= 148, 16 at hop <= 307
 constexpr int TAB_WIN = 0, TAB_TW256 = 512, TAB_TW512 = 1024, TAB_FLOATS = 1536;
+// A frame's LDS tile (FRAME_LDS_FLOATS = 2304 B) is a multiple of the 256-byte bank row, so the two frames of a half-wave
+// hit the same banks with every 64-bit tile access; 128 bytes of slack between tiles put neighbouring frames on
+// opposite halves of the banks.
+constexpr int FRAME_STRIDE = FRAME_LDS_FLOATS + 32;
 
 struct LogmelParams {
     const float* wave;
@@ -64,9 +68,9 @@ __global__ void __launch_bounds__(WG, 2) logmel_kernel(LogmelParams p) {
     float* tw512 = win + NFFT;                     // 256 x (cos, -sin)
     float* samp = tw512 + NFFT;                    // nsamp (rounded up to 4)
     float* work = samp + ((nsamp + 3) & ~3);       // 16 frames x FRAME_LDS_FLOATS
-    float* ostage = work + 16 * FRAME_LDS_FLOATS;  // fpb x opitch  (+ fpb denominators)
+    float* ostage = work + 16 * FRAME_STRIDE;      // fpb x opitch  (+ fpb denominators)
     // filterbank tables behind the staging area, 16-byte aligned: start4 | quads | off | padded weights
-    int* fbi = reinterpret_cast<int*>(sm + ((2 * NFFT + ((nsamp + 3) & ~3) + 16 * FRAME_LDS_FLOATS + p.fpb * opitch + p.fpb + 3) & ~3));
+    int* fbi = reinterpret_cast<int*>(sm + ((2 * NFFT + ((nsamp + 3) & ~3) + 16 * FRAME_STRIDE + p.fpb * opitch + p.fpb + 3) & ~3));
     const int* fb_start = p.fb_start;
     const int* fb_len = p.fb_len;
     const int* fb_off = p.fb_off;
@@ -91,7 +95,7 @@ __global__ void __launch_bounds__(WG, 2) logmel_kernel(LogmelParams p) {
         tw512[i] = p.tabs[TAB_TW512 + i];
     }
 
-    float* mybuf = work + (wave * 4 + grp) * FRAME_LDS_FLOATS;
+    float* mybuf = work + (wave * 4 + grp) * FRAME_STRIDE;
     const int n_mel_iter = (p.n_mels + 15) >> 4;
 
     // The samples of a block travel global -> registers -> LDS: the loads of the NEXT block are issued
@@ -236,7 +240,7 @@ __global__ void __launch_bounds__(WG, 2) logmel_kernel(LogmelParams p) {
 // LDS bytes of one workgroup of `fpb` frames (kernel layout), with `fb_ints` words of filterbank tables
 size_t lds_bytes(int fpb, int hop, int n_mels, size_t fb_ints) {
     const int nsamp = (fpb - 1) * hop + NFFT;
-    return sizeof(float) * ((size_t)2 * NFFT + ((nsamp + 3) & ~3) + 16 * FRAME_LDS_FLOATS + (size_t)fpb * (n_mels + 1) + fpb) +
+    return sizeof(float) * ((size_t)2 * NFFT + ((nsamp + 3) & ~3) + 16 * FRAME_STRIDE + (size_t)fpb * (n_mels + 1) + fpb) +
            fb_ints * 4 + 16;
 }
 constexpr size_t LDS_TWO_PER_CU = 80 * 1024;  // two workgroups of this size share a CU

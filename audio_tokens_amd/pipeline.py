@@ -116,6 +116,11 @@ class DevicePipeline:
         sync(); secs["tokenize"] = time.perf_counter() - t0
 
         # the only host round trips of the pass, behind everything that was queued
+        if self.world > 1:   # (every rank must take the same decision, or the others would wait in the next collective)
+            import torch.distributed as dist
+            flag = bad.cpu() if dist.get_backend(self.process_group) == "gloo" else bad
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.process_group)
+            bad = flag
         if bool(bad.item()):
             raise RuntimeError("Error: 'std::isfinite(x_in[i])' failed: input contains NaN's or Inf's")
         stats = [km._read_stats(*p) for p in pending if p is not None]
