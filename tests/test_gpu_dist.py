@@ -130,3 +130,70 @@ def test_two_ranks_one_gpu(oracle, be):
     assert np.array_equal(bits(res[0]["pipe_centroids"]), bits(cent))
     ids, _ = oracle.assign(frames, cent)
     assert np.array_equal(res[0]["pipe_tokens"], ids[0:2 * T]) and np.array_equal(res[1]["pipe_tokens"], ids[3 * T:5 * T])
+
+
+def _rccl_single_rank_worker(port, q):
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import audio_tokens_amd.ops as ops
+        from audio_tokens_amd.backend import default_backend
+        be = default_backend()
+
+        class OneRankRccl(ops._Dist):   # a one-rank group still goes through every collective of the sharded path
+            def __init__(self, enabled, group=None):
+                super().__init__(enabled, group)
+                self.on, self.world, self.rank, self.host_staged = bool(enabled), 1, 0, False
+
+        d = OneRankRccl(True)
+        out = {"backend": dist.get_backend()}
+        v = torch.randn(100003, device="cuda")
+        out["gather"] = bool(torch.equal(d.all_gather_parts(v)[0], v))
+        out["scatter"] = bool(torch.equal(d.reduce_in_rank_order(be, v), v))
+        out["sizes"] = d.all_gather_sizes(77, be.device)
+        out["flag"] = d.any_flag(True, be.device)
+        out["f64"] = float(d.all_gather_f64(torch.tensor([1.25], dtype=torch.float64, device="cuda"))[0])
+        rows = torch.randn(5, 8, device="cuda")
+        out["bits"] = bool(torch.equal(d.sum_bits(rows.clone()), rows))
+        # and a whole training through the distributed code path (device collectives, no host staging)
+        rng = np.random.default_rng(3)
+        x = rng.standard_normal((50000, 64)).astype(np.float32)
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        plain = ops.Kmeans(64, 1024, niter=5)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            plain.train(x)
+            ops._Dist = OneRankRccl
+            for exchange in ("gather", "scatter"):
+                km = ops.Kmeans(64, 1024, niter=5, distributed=True)
+                km.exchange = exchange
+                km.train(x)
+                out[exchange + "_train"] = bool(np.array_equal(bits(km.centroids), bits(plain.centroids)))
+        q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_collectives_execute_with_one_rank(be):
+    """The pool's boxes have one GPU, and RCCL refuses two ranks on one device, so the two-rank test above runs over
+    gloo there.  This one makes the `nccl` branch of ops._Dist execute anyway: a one-rank RCCL group, device tensors
+    through every collective the sharded k-means uses (all-gather, all-to-all, all-reduce), and a whole training
+    through the distributed code path in both exchange forms -- which with one shard must equal the plain training."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_single_rank_worker, args=(_free_port(), q))
+    p.start()
+    out = q.get(timeout=300)
+    p.join(60)
+    assert p.exitcode == 0
+    assert out["backend"] == "nccl"
+    assert out["gather"] and out["scatter"] and out["bits"] and out["flag"] is True
+    assert out["sizes"] == [77] and out["f64"] == 1.25
+    assert out["gather_train"] and out["scatter_train"]
