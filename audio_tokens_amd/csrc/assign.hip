@@ -1322,13 +1322,15 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
         }
         rcp = at_filter_use_slot_events(ctx, slot);
         if (rcp) return rcp;
-        unsigned* misc = static_cast<unsigned*>(at_ws(ctx, WS_FILTER_MISC, 256, stream));
-        uint32_t* list = static_cast<uint32_t*>(at_ws(ctx, WS_FILTER_LIST, sizeof(uint32_t) * 5 * ((size_t)n + 64), stream));
+        unsigned* misc = static_cast<unsigned*>(at_ws(ctx, WS_FILTER_MISC, 1024, stream));
+        const size_t lstride = at_amb_stride(n);   // five arrays of 64 sub-lists: list | sorted | order | hints | aux
+        const unsigned amb_cap = at_amb_cap(n);
+        uint32_t* list = static_cast<uint32_t*>(at_ws(ctx, WS_FILTER_LIST, sizeof(uint32_t) * 5 * lstride, stream));
         if (!misc || !list) return AT_E_NOMEM;
-        uint32_t* aux = list + 4 * ((size_t)n + 64);
+        uint32_t* aux = list + 4 * lstride;
         int rc = at_filter_sweep(ctx, x, n, D, c, k, order, cperm, ng, bd, mask, ngw, mode == 0 ? 1 : 0, ids, misc, list,
                                  aux, nullptr, fuse ? hint_sorted : nullptr, fuse ? dmin : nullptr, fuse ? bd : nullptr,
-                                 (fuse || mode != 0) ? dist : nullptr, stream);
+                                 (fuse || mode != 0) ? dist : nullptr, amb_cap, stream);
         if (rc) return rc;
         if (dist && fuse) {  // the sweep wrote the guess distances; the rows that moved get theirs here
             rc = at_exact_dist_todo(ctx, x, n, D, c, k, ids, dist, stream);
@@ -1349,24 +1351,24 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
             int64_t wgs = n / 64;                      // enough workgroups for a list of 1.5 % of the rows in one go
             if (wgs < 256) wgs = 256;
             if (wgs > 65535) wgs = 65535;
-            rc = at_filter_redo_rows(ctx, x, D, c, k, list, wgs, order, cperm, dmin, ng, misc, aux, ids, dist, misc + 1, stream);
+            rc = at_filter_redo_rows(ctx, x, D, c, k, list, wgs, order, cperm, dmin, ng, misc, aux, ids, dist, misc + 64, amb_cap,
+                                     stream);
             if (rc) return rc;
-            AT_HIP(hipMemcpyAsync(fs.host_misc, misc, 64 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+            AT_HIP(hipMemcpyAsync(fs.host_misc, misc, 128 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
             AT_HIP(hipEventRecord(fs.copied, stream));
             fs.rows = n;
             ctx->fring_count++;
             return AT_OK;
         }
-        unsigned host_misc[64];
+        unsigned host_misc[128];
         AT_HIP(hipMemcpyAsync(host_misc, misc, sizeof host_misc, hipMemcpyDeviceToHost, stream));
         AT_HIP(hipStreamSynchronize(stream));
-        const unsigned listed = host_misc[1];
+        unsigned listed = 0;
+        for (unsigned s2 = 0; s2 < AT_AMB_SUBLISTS; s2++) listed += host_misc[64 + s2];
         ctx->filter_rows += n;
         ctx->filter_listed += listed;
-        for (int i = 0; i < 16; i++) {
-            ctx->filter_tiles += host_misc[4 + 2 * i];
-            ctx->filter_refined += host_misc[5 + 2 * i];
-        }
+        ctx->filter_tiles += host_misc[4];
+        ctx->filter_refined += host_misc[5];
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, ctx->filter_ev[0], ctx->filter_ev[1]) == hipSuccess) {
             ctx->filter_ms += ms;
@@ -1374,16 +1376,24 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
         }
         if ((int64_t)listed * 16 <= n) ctx->filter_force_sync = 0;   // the data behave again
         if (listed == 0) return AT_OK;
-        // short lists: one workgroup per row on the vector ALU; long ones (badly conditioned data,
-        // centroids outside the fp16 range): the fp32 MFMA sweep over the listed rows
-        if ((int64_t)listed * 16 <= n)
-            return at_filter_redo_rows(ctx, x, D, c, k, list, listed, order, cperm, dmin, ng, misc, aux, ids, dist, nullptr, stream);
+        // short lists: one workgroup per row on the vector ALU (it walks the sub-lists itself); long ones (badly
+        // conditioned data, centroids outside the fp16 range): the fp32 MFMA sweep over the listed rows, which wants
+        // them in one piece
+        if ((int64_t)listed * 16 <= n) {
+            int64_t wgs = listed < 65535u ? (int64_t)listed : 65535;
+            return at_filter_redo_rows(ctx, x, D, c, k, list, wgs, order, cperm, dmin, ng, misc, aux, ids, dist, misc + 64, amb_cap,
+                                       stream);
+        }
         rc = prep_fp32_image();
         if (rc) return rc;
         n2 = listed < 64 ? 64 : (int64_t)listed;
-        uint32_t* sorted = list + ((size_t)n + 64);
-        uint32_t* order_amb = sorted + ((size_t)n + 64);
-        uint32_t* hint_amb = order_amb + ((size_t)n + 64);
+        uint32_t* sorted = list + lstride;
+        uint32_t* order_amb = sorted + lstride;
+        uint32_t* hint_amb = order_amb + lstride;
+        // (listed <= n < the stride: the contiguous copy fits the `sorted` / `order` arrays; it then moves to the front of `list`)
+        rc = at_amb_compact(ctx, misc, amb_cap, list, aux, sorted, order_amb, stream);
+        if (rc) return rc;
+        AT_HIP(hipMemcpyAsync(list, sorted, sizeof(uint32_t) * listed, hipMemcpyDeviceToDevice, stream));
         rc = at_filter_gather_ambiguous(ctx, list, sorted, listed, n2, order, ids, order_amb, hint_amb, stream);
         if (rc) return rc;
         order2 = order_amb;
@@ -1456,9 +1466,9 @@ extern "C" int at_prune_mask_f32(at_ctx* ctx, const float* x, int64_t n, int d, 
 // Folds the statistics words an asynchronous exact call left in pinned memory into the totals.
 int at_filter_use_slot_events(at_ctx* ctx, int slot) {
     if (!ctx->filter_host_misc) {
-        AT_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->filter_host_misc), (size_t)(AT_FILTER_RING + 1) * 64 * sizeof(unsigned),
+        AT_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->filter_host_misc), (size_t)(AT_FILTER_RING + 1) * 128 * sizeof(unsigned),
                              hipHostMallocDefault));
-        for (int s = 0; s <= AT_FILTER_RING; s++) ctx->fring[s].host_misc = ctx->filter_host_misc + (size_t)s * 64;
+        for (int s = 0; s <= AT_FILTER_RING; s++) ctx->fring[s].host_misc = ctx->filter_host_misc + (size_t)s * 128;
     }
     at_filter_slot& fs = ctx->fring[slot];
     if (!fs.copied) AT_HIP(hipEventCreateWithFlags(&fs.copied, hipEventDisableTiming));
@@ -1481,13 +1491,12 @@ int at_filter_resolve_pending(at_ctx* ctx, bool wait_all) {
             AT_HIP(q);
         }
         const unsigned* hm = fs.host_misc;
-        const unsigned listed = hm[1];
+        unsigned listed = 0;
+        for (unsigned s2 = 0; s2 < AT_AMB_SUBLISTS; s2++) listed += hm[64 + s2];
         ctx->filter_rows += fs.rows;
         ctx->filter_listed += listed;
-        for (int i = 0; i < 16; i++) {
-            ctx->filter_tiles += hm[4 + 2 * i];
-            ctx->filter_refined += hm[5 + 2 * i];
-        }
+        ctx->filter_tiles += hm[4];
+        ctx->filter_refined += hm[5];
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, fs.ev[0], fs.ev[1]) == hipSuccess) {
             ctx->filter_ms += ms;
@@ -1536,17 +1545,20 @@ extern "C" int at_filter_probe_f32(at_ctx* ctx, const float* x, int64_t n, int d
     const int64_t ntile32 = (n + 31) / 32;
     float* bd = static_cast<float*>(at_ws(ctx, WS_PRUNE_BD, sizeof(float) * (size_t)n, stream));
     uint32_t* mask = static_cast<uint32_t*>(at_ws(ctx, WS_PRUNE_MASK, sizeof(uint32_t) * (size_t)ntile32 * ngw, stream));
-    unsigned* misc = static_cast<unsigned*>(at_ws(ctx, WS_FILTER_MISC, 256, stream));
-    uint32_t* list = static_cast<uint32_t*>(at_ws(ctx, WS_FILTER_LIST, sizeof(uint32_t) * 5 * ((size_t)n + 64), stream));
+    unsigned* misc = static_cast<unsigned*>(at_ws(ctx, WS_FILTER_MISC, 1024, stream));
+    const size_t lstride = at_amb_stride(n);
+    uint32_t* list = static_cast<uint32_t*>(at_ws(ctx, WS_FILTER_LIST, sizeof(uint32_t) * 5 * lstride, stream));
     if (!bd || !mask || !misc || !list) return AT_E_NOMEM;
     int rc = at_prune_prepass(ctx, x, n, d, c, k, order, hint_sorted, dmin, ng, bd, mask, ngw, 0, stream);
     if (rc) return rc;
     rc = at_filter_sweep(ctx, x, n, d, c, k, order, cperm, ng, bd, mask, ngw, 1, ids, misc, list,
-                         list + 4 * ((size_t)n + 64), approx, nullptr, nullptr, nullptr, nullptr, stream);
+                         list + 4 * lstride, approx, nullptr, nullptr, nullptr, nullptr, at_amb_cap(n), stream);
     if (rc) return rc;
-    unsigned cnt = 0;
-    AT_HIP(hipMemcpyAsync(&cnt, misc + 1, sizeof cnt, hipMemcpyDeviceToHost, stream));
+    unsigned cnts[AT_AMB_SUBLISTS];
+    AT_HIP(hipMemcpyAsync(cnts, misc + 64, sizeof cnts, hipMemcpyDeviceToHost, stream));
     AT_HIP(hipStreamSynchronize(stream));
+    int64_t cnt = 0;
+    for (unsigned s2 = 0; s2 < AT_AMB_SUBLISTS; s2++) cnt += cnts[s2];
     *listed = cnt;
     return AT_OK;
 }

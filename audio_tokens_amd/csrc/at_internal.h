@@ -51,6 +51,7 @@ enum at_ws_slot {
     WS_LONG_LATE,      // centroid_accum: long clusters left to the pass behind the sort
     WS_BUCKETS,        // centroid_accum bucket path: counts, cursors, the list of long clusters
     WS_LOGMEL_ANY,     // log-mel, general n_fft: window, twiddles, banded filterbank
+    WS_FILTER_BLKSTATS, // fp16-split filter: one statistics record per workgroup of a sweep (switch filter_stats)
     WS_NSLOTS
 };
 
@@ -79,6 +80,7 @@ struct at_debug {
     int filter_wps2;      // AT_FILTER_WPS2      1 = two waves per SIMD in the Lloyd-sized filter sweeps
     int dmin_kernel;      // AT_DMIN_KERNEL      0 = fp32 vector-ALU kernel for the centroid-to-group bounds
     int resample_simple;  // AT_RESAMPLE_SIMPLE  1 = one-thread-per-sample resampler
+    int filter_stats;     // AT_FILTER_STATS     1 = the sweeps count accumulators / tiles for at_prune_stats, at_filter_stats
     int accum_buckets;    // AT_ACCUM_BUCKETS    0 = member lists by radix sort (the only form for k > 16 384)
 };
 
@@ -160,7 +162,14 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
                     const int32_t* cperm, int ng, const float* bd, const uint32_t* mask, int ngw, int collect,
                     int64_t* ids, unsigned* misc, uint32_t* amb_list, uint32_t* amb_aux, float* approx_out,
                     const uint32_t* fuse_hint_sorted, const float* fuse_dmin, float* fuse_bd_out, float* fuse_dist_out,
-                    hipStream_t stream);
+                    unsigned amb_cap, hipStream_t stream);
+// the rows a sweep lists for the redo: 64 sub-lists of amb_cap slots each (counters at misc[64 ..]), arrays of
+// at_amb_stride(n) words
+constexpr unsigned AT_AMB_SUBLISTS = 64;
+static inline unsigned at_amb_cap(int64_t n) { return (unsigned)(n / AT_AMB_SUBLISTS + 128); }
+static inline size_t at_amb_stride(int64_t n) { return (size_t)at_amb_cap(n) * AT_AMB_SUBLISTS; }
+int at_amb_compact(at_ctx* ctx, const unsigned* misc, unsigned amb_cap, const uint32_t* list, const uint32_t* aux,
+                   uint32_t* list_out, uint32_t* aux_out, hipStream_t stream);
 int at_exact_dist_todo(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k, const int64_t* ids,
                        float* dist, hipStream_t stream);
 int at_exact_dist_rows(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k, const int64_t* ids,
@@ -172,7 +181,8 @@ int at_filter_gather_ambiguous(at_ctx* ctx, uint32_t* amb_list, uint32_t* amb_so
 
 int at_filter_redo_rows(at_ctx* ctx, const float* x, int d, const float* c, int k, const uint32_t* list, int64_t m,
                         const uint32_t* order, const int32_t* cperm, const float* dmin, int ng, const unsigned* misc,
-                        const uint32_t* aux, int64_t* ids, float* dist, const unsigned* count_dev, hipStream_t stream);
+                        const uint32_t* aux, int64_t* ids, float* dist, const unsigned* count_dev, unsigned amb_cap,
+                        hipStream_t stream);
 
 // logmel_any.hip: every power-of-two n_fft other than 512
 int at_logmel_any(at_ctx* ctx, const float* wave, int64_t n_clips, int64_t L, int64_t wave_stride, int sample_rate,

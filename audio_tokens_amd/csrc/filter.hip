@@ -119,7 +119,7 @@ struct FusedPrepass {
     const float* dmin;
     float* bd_out;
     float* dist_out;   // optional: the guess distance where the winner is the guess, DIST_TODO elsewhere
-    unsigned long long* stats;
+    unsigned long long* stats;   // (unused by the sweep since round 2: see blk_stats)
     int k;
     // guess generator over rows in their own order (frames of clips): nearest group mean first, then the
     // groups its neighbour table names -- both inside one launch
@@ -128,6 +128,7 @@ struct FusedPrepass {
     int ngm;
 };
 constexpr unsigned DIST_TODO = 0x7fc0deadu;  // a NaN no computed distance can be
+constexpr unsigned AMB_SUBLISTS = 64;      // the rows a sweep lists for the redo are appended to 64 sub-lists
 
 template <int D, int NB, bool GUESS, bool FUSED, int WPS = 2>
 __global__ void __launch_bounds__(64, WPS)
@@ -136,8 +137,12 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
                         const uint32_t* __restrict__ mask, int ngw, unsigned* __restrict__ misc, float tau_a,
                         float tau_b, float rho_a, float rho_b, int screen, int collect, long* __restrict__ ids,
                         uint32_t* __restrict__ amb_list, uint32_t* __restrict__ amb_aux,
-                        float* __restrict__ approx_out, FusedPrepass fp) {
+                        float* __restrict__ approx_out, FusedPrepass fp, uint4* __restrict__ blk_stats, unsigned amb_cap) {
     static_assert(NB == 2 || NB == 4, "tiles are processed in pairs");
+    // blk_stats (may be null = statistics off): one record per workgroup {groups needed, groups of the dense sweep,
+    // tiles multiplied hi*hi, tiles refined}, summed by filter_stats_reduce_kernel.  Round 1 added these with
+    // atomics on 16 + 256 hot words from all 32 768 workgroups of a Lloyd sweep: 40 us of a 600 us kernel.
+    unsigned st_needed = 0, st_total = 0;
     constexpr int NS = D / 16;
     constexpr size_t GB = group_bytes(D);
     __shared__ unsigned short glist[512];
@@ -326,13 +331,12 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
                 else need[b][it] = 0ull;
             }
         }
-        if (lane == 0) {  // statistics only (256 slots to keep the atomics off one address)
-            unsigned long long* slot = fp.stats + 2 * (blockIdx.x & 255);
+        {
             int tiles_here = 0;
 #pragma unroll
             for (int b = 0; b < NB; b++) tiles_here += pos0 + 32 * b < n;
-            atomicAdd(&slot[0], (unsigned long long)needed_total);
-            atomicAdd(&slot[1], (unsigned long long)ng * tiles_here);
+            st_needed = (unsigned)needed_total;
+            st_total = (unsigned)(ng * tiles_here);
         }
 #pragma unroll
         for (int it = 0; it < 8; it++) {
@@ -597,10 +601,7 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
         }
     }
 
-    if (lane == 0) {  // statistics only, spread over 16 slot pairs
-        atomicAdd(&misc[4 + 2 * (blockIdx.x & 15)], n_hh);
-        atomicAdd(&misc[5 + 2 * (blockIdx.x & 15)], n_ref);
-    }
+    if (lane == 0 && blk_stats) blk_stats[blockIdx.x] = make_uint4(st_needed, st_total, n_hh, n_ref);
     auto slot_id = [&](unsigned slot) {
         return slot == NONE ? NONE
                             : reinterpret_cast<const unsigned*>(img_cur + (size_t)(slot >> 5) * GB + misc_off(D) + 128)[slot & 31];
@@ -652,9 +653,12 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
         if (collect) {
             const unsigned long long flagged = __builtin_amdgcn_ballot_w64(mine && !unique);
             if (flagged != 0) {
+                // 64 sub-lists (workgroup b appends to list b % 64, each with its own counter misc[64 + s] and amb_cap
+                // slots): one counter for all 23 000 appending workgroups of a Lloyd sweep was a 30 us queue
+                const unsigned sub = blockIdx.x & (AMB_SUBLISTS - 1);
                 unsigned base = 0;
-                if (lane == 0) base = atomicAdd(&misc[1], (unsigned)__builtin_popcountll(flagged));
-                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                if (lane == 0) base = atomicAdd(&misc[64 + sub], (unsigned)__builtin_popcountll(flagged));
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + sub * amb_cap;
                 if (mine && !unique) {
                     const unsigned rank = (unsigned)__builtin_popcountll(flagged & ((1ull << lane) - 1ull));
                     amb_list[base + rank] = (uint32_t)pos;
@@ -789,6 +793,71 @@ __global__ void __launch_bounds__(WG) gather_ambiguous_kernel(const uint32_t* __
     hint_amb[i] = id >= 0 ? (uint32_t)id : NONE;
 }
 
+// sums the per-workgroup records of a sweep into the statistics words (stats[0..1]: 64-bit, misc[4..5])
+__global__ void __launch_bounds__(1024) filter_stats_reduce_kernel(const uint4* __restrict__ rec, unsigned n_rec,
+                                                                   unsigned long long* __restrict__ stats,
+                                                                   unsigned* __restrict__ misc) {
+    __shared__ unsigned long long part[4][16];
+    unsigned long long a = 0, b = 0, c = 0, d = 0;
+    for (unsigned i = threadIdx.x; i < n_rec; i += 1024) {
+        const uint4 r = rec[i];
+        a += r.x; b += r.y; c += r.z; d += r.w;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off); b += __shfl_down(b, off); c += __shfl_down(c, off); d += __shfl_down(d, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        part[0][w] = a; part[1][w] = b; part[2][w] = c; part[3][w] = d;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t[4] = {0, 0, 0, 0};
+        for (int q = 0; q < 4; q++)
+            for (int w = 0; w < 16; w++) t[q] += part[q][w];
+        if (stats) { atomicAdd(&stats[0], t[0]); atomicAdd(&stats[1], t[1]); }
+        atomicAdd(&misc[4], (unsigned)t[2]);
+        atomicAdd(&misc[5], (unsigned)t[3]);
+    }
+}
+
+// The listed rows live in AMB_SUBLISTS sub-lists of amb_cap slots (counters at misc[64 ..]).  lds_prefix[s] = entries
+// before sub-list s, lds_prefix[64] = all of them; entry e of the concatenation sits at slot amb_slot(e).
+__device__ __forceinline__ unsigned amb_prefix(const unsigned* __restrict__ misc, unsigned* lds_prefix) {
+    if (threadIdx.x < 64) {
+        const unsigned c = misc[64 + threadIdx.x];
+        unsigned x = c;
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned y = __shfl_up(x, off);
+            if ((int)threadIdx.x >= off) x += y;
+        }
+        lds_prefix[threadIdx.x] = x - c;
+        if (threadIdx.x == 63) lds_prefix[64] = x;
+    }
+    __syncthreads();
+    return lds_prefix[64];
+}
+__device__ __forceinline__ unsigned amb_slot(const unsigned* lds_prefix, unsigned amb_cap, unsigned e) {
+    unsigned lo = 0;
+#pragma unroll
+    for (unsigned step = 32; step > 0; step >>= 1)
+        if (lds_prefix[lo + step] <= e) lo += step;
+    return lo * amb_cap + (e - lds_prefix[lo]);
+}
+
+// sub-lists -> one contiguous list (the synchronous form of the exact call, whose long lists are sorted and swept)
+__global__ void __launch_bounds__(WG) amb_compact_kernel(const unsigned* __restrict__ misc, unsigned amb_cap,
+                                                         const uint32_t* __restrict__ list, const uint32_t* __restrict__ aux,
+                                                         uint32_t* __restrict__ list_out, uint32_t* __restrict__ aux_out) {
+    __shared__ unsigned pre[65];
+    const unsigned total = amb_prefix(misc, pre);
+    for (unsigned e = blockIdx.x * WG + threadIdx.x; e < total; e += gridDim.x * WG) {
+        const unsigned sl = amb_slot(pre, amb_cap, e);
+        list_out[e] = list[sl];
+        aux_out[e] = aux[sl];
+    }
+}
+
 // Redo of ONE listed row per workgroup, on the vector ALU: the row's own Elkan test (the per-row
 // criterion of prune_mask_kernel, with the filter's winner as the guess) picks the groups, every
 // thread evaluates the contract's distance (the same three fmaf chains as everywhere else) for a few
@@ -803,19 +872,24 @@ __global__ void __launch_bounds__(WG) exact_rows_kernel(const float* __restrict_
                                                         const float* __restrict__ dmin, int ng,
                                                         const unsigned* __restrict__ misc,
                                                         const uint32_t* __restrict__ aux, long* __restrict__ ids,
-                                                        float* __restrict__ dist, const unsigned* __restrict__ count_dev) {
+                                                        float* __restrict__ dist, const unsigned* __restrict__ count_dev,
+                                                        unsigned amb_cap) {
     __shared__ int needed[512];
     __shared__ int n_needed;
     __shared__ float red_d[WG / 64];
     __shared__ unsigned red_i[WG / 64];
+    __shared__ unsigned pre[65];
     const int tid = threadIdx.x;
-    // entry = blockIdx.x; with count_dev the list length is read on the device and the grid strides
-    // over it (the launch then needs no host round trip; blocks beyond the list leave at once)
-    const unsigned count = count_dev ? *count_dev : gridDim.x;
+    // count_dev given (the asynchronous exact call): the entries are the concatenation of the sweep's sub-lists, whose
+    // lengths are read here, on the device, and the grid strides over them (no host round trip; workgroups beyond the
+    // list leave at once).  Otherwise: a contiguous list of gridDim.x entries.
+    const bool sub = count_dev != nullptr;
+    const unsigned count = sub ? amb_prefix(misc, pre) : gridDim.x;
     // Entries for which the filter left exactly two candidates need two chains, not a workgroup: one
     // thread each, before the workgroup-per-row loop (which then passes over them).
     if (aux) {
-        for (unsigned entry = blockIdx.x * WG + tid; entry < count; entry += gridDim.x * WG) {
+        for (unsigned entry_e = blockIdx.x * WG + tid; entry_e < count; entry_e += gridDim.x * WG) {
+            const unsigned entry = sub ? amb_slot(pre, amb_cap, entry_e) : entry_e;
             const uint32_t second = aux[entry];
             if (second >= (uint32_t)k) continue;
             const long row = order[list[entry]];
@@ -844,7 +918,8 @@ __global__ void __launch_bounds__(WG) exact_rows_kernel(const float* __restrict_
             if (dist) dist[row] = take2 ? d2 : d1;
         }
     }
-    for (unsigned entry = blockIdx.x; entry < count; entry += gridDim.x) {
+    for (unsigned entry_e = blockIdx.x; entry_e < count; entry_e += gridDim.x) {
+    const unsigned entry = sub ? amb_slot(pre, amb_cap, entry_e) : entry_e;
     const long row = order[list[entry]];
     const uint32_t second = aux ? aux[entry] : NONE;
     const long p = ids[row];
@@ -1040,13 +1115,21 @@ void filter_rho(int d, float* rho_a, float* rho_b) {
 
 size_t at_filter_group_bytes(int d) { return group_bytes(d); }
 
+int at_amb_compact(at_ctx* ctx, const unsigned* misc, unsigned amb_cap, const uint32_t* list, const uint32_t* aux,
+                   uint32_t* list_out, uint32_t* aux_out, hipStream_t stream) {
+    (void)ctx;
+    hipLaunchKernelGGL(amb_compact_kernel, dim3(256), dim3(WG), 0, stream, misc, amb_cap, list, aux, list_out, aux_out);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}
+
 // Stage 1: image + sweep.  misc (device, 2 words) receives max|c|^2 and the number of listed rows;
 // amb_list receives their visiting positions (unordered).
 int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k, const uint32_t* order,
                     const int32_t* cperm, int ng, const float* bd, const uint32_t* mask, int ngw, int collect,
                     int64_t* ids, unsigned* misc, uint32_t* amb_list, uint32_t* amb_aux, float* approx_out,
                     const uint32_t* fuse_hint_sorted, const float* fuse_dmin, float* fuse_bd_out, float* fuse_dist_out,
-                    hipStream_t stream) {
+                    unsigned amb_cap, hipStream_t stream) {
     unsigned char* img = static_cast<unsigned char*>(at_ws(ctx, WS_CENT_IMG16, group_bytes(d) * (size_t)ng, stream));
     if (!img) return AT_E_NOMEM;
     // fused pre-pass (exact calls only): the sweep computes the guess distances and its own group masks
@@ -1064,10 +1147,10 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
                        ctx->img16_d == d && ctx->img16_ng == ng && misc == ctx->img16_misc;
     ctx->img16_trusted = 0;
     if (reuse) {
-        AT_HIP(hipMemsetAsync(misc + 1, 0, 63 * sizeof(unsigned), stream));  // list length, statistics
+        AT_HIP(hipMemsetAsync(misc + 1, 0, 127 * sizeof(unsigned), stream));  // statistics, sub-list lengths
     } else {
         ctx->img16_c = nullptr;
-        AT_HIP(hipMemsetAsync(misc, 0, 64 * sizeof(unsigned), stream));  // max|c|^2, list length, statistics
+        AT_HIP(hipMemsetAsync(misc, 0, 128 * sizeof(unsigned), stream));  // max|c|^2, statistics, sub-list lengths
         hipLaunchKernelGGL(prep_centroids_f16_kernel, dim3(ng), dim3(WG), 0, stream, c, k, d, cperm, img, misc);
         AT_LAUNCH_CHECK();
     }
@@ -1084,7 +1167,14 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
     const int NB = (wps3 || nbv == 2) ? 2 : 4;
     const dim3 grid((unsigned)((n + 32 * NB - 1) / (32 * NB)));
     AT_REQUIRE(d == 64 || d == 128, "at_filter_sweep: d must be 64 or 128");
-    if (collect) {  // exact calls synchronise anyway: time the kernel for at_filter_stats
+    // statistics (switch filter_stats; off by default): one record per workgroup, summed behind the sweep
+    const unsigned n_wg = d == 128 ? (unsigned)((n + 63) / 64) : grid.x;
+    uint4* blk_stats = nullptr;
+    if (ctx->dbg.filter_stats) {
+        blk_stats = static_cast<uint4*>(at_ws(ctx, WS_FILTER_BLKSTATS, (size_t)n_wg * sizeof(uint4), stream));
+        if (!blk_stats) return AT_E_NOMEM;
+    }
+    if (collect) {  // exact calls: time the kernel for at_filter_stats
         if (!ctx->filter_ev[0]) {   // (a caller that did not pick a ring slot: the spare pair)
             int rce = at_filter_use_slot_events(ctx, AT_FILTER_RING);
             if (rce) return rce;
@@ -1094,7 +1184,7 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
 #define AT_FILTER_LAUNCH(DD, NBB, GG, FF, GRID)                                                                      \
     hipLaunchKernelGGL((assign_f16filter_kernel<DD, NBB, GG, FF>), GRID, dim3(64), 0, stream, x, (long)n, img, ng, order, \
                        bd, mask, ngw, misc, ta, tb, ra, rb, screen, collect, reinterpret_cast<long*>(ids), amb_list,      \
-                       amb_aux, approx_out, fp)
+                       amb_aux, approx_out, fp, blk_stats, amb_cap)
     // exact calls (collect) and guess generators are separate instantiations: the guess path's code
     // would otherwise cost the exact sweep registers it does not have
     const dim3 grid64((unsigned)((n + 63) / 64));
@@ -1110,7 +1200,7 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
         if (wps3) {
             hipLaunchKernelGGL((assign_f16filter_kernel<64, 2, false, true, 3>), grid, dim3(64), 0, stream, x, (long)n, img, ng,
                                order, bd, mask, ngw, misc, ta, tb, ra, rb, screen, collect, reinterpret_cast<long*>(ids),
-                               amb_list, amb_aux, approx_out, fp);
+                               amb_list, amb_aux, approx_out, fp, blk_stats, amb_cap);
         } else if (fused) AT_FILTER_LAUNCH(64, 2, false, true, grid);
         else if (collect) AT_FILTER_LAUNCH(64, 2, false, false, grid);
         else AT_FILTER_LAUNCH(64, 2, true, false, grid);
@@ -1118,6 +1208,10 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
 #undef AT_FILTER_LAUNCH
     AT_LAUNCH_CHECK();
     if (collect) AT_HIP(hipEventRecord(ctx->filter_ev[1], stream));
+    if (blk_stats) {
+        hipLaunchKernelGGL(filter_stats_reduce_kernel, dim3(1), dim3(1024), 0, stream, blk_stats, n_wg, fused ? fp.stats : nullptr, misc);
+        AT_LAUNCH_CHECK();
+    }
     return AT_OK;
 }
 
@@ -1166,16 +1260,17 @@ int at_filter_gather_ambiguous(at_ctx* ctx, uint32_t* amb_list, uint32_t* amb_so
 // Stage 2 for short lists: one workgroup per listed row (see exact_rows_kernel).
 int at_filter_redo_rows(at_ctx* ctx, const float* x, int d, const float* c, int k, const uint32_t* list, int64_t m,
                         const uint32_t* order, const int32_t* cperm, const float* dmin, int ng, const unsigned* misc,
-                        const uint32_t* aux, int64_t* ids, float* dist, const unsigned* count_dev, hipStream_t stream) {
+                        const uint32_t* aux, int64_t* ids, float* dist, const unsigned* count_dev, unsigned amb_cap,
+                        hipStream_t stream) {
     (void)ctx;
     if (m <= 0) return AT_OK;   // m = list length, or (with count_dev) the number of workgroups to launch
     AT_REQUIRE(ng <= 512, "at_filter_redo_rows: ng > 512");
     if (d == 64)
         hipLaunchKernelGGL(exact_rows_kernel<64>, dim3((unsigned)m), dim3(WG), 0, stream, x, c, k, list, order, cperm, dmin,
-                           ng, misc, aux, reinterpret_cast<long*>(ids), dist, count_dev);
+                           ng, misc, aux, reinterpret_cast<long*>(ids), dist, count_dev, amb_cap);
     else
         hipLaunchKernelGGL(exact_rows_kernel<128>, dim3((unsigned)m), dim3(WG), 0, stream, x, c, k, list, order, cperm,
-                           dmin, ng, misc, aux, reinterpret_cast<long*>(ids), dist, count_dev);
+                           dmin, ng, misc, aux, reinterpret_cast<long*>(ids), dist, count_dev, amb_cap);
     AT_LAUNCH_CHECK();
     return AT_OK;
 }
@@ -1183,7 +1278,7 @@ int at_filter_redo_rows(at_ctx* ctx, const float* x, int d, const float* c, int 
 int at_group_min_dist_f16(at_ctx* ctx, const float* c, int k, int d, const int32_t* cperm, int ng, float* dmin,
                           hipStream_t stream) {
     unsigned char* img = static_cast<unsigned char*>(at_ws(ctx, WS_CENT_IMG16, group_bytes(d) * (size_t)ng, stream));
-    unsigned* misc = static_cast<unsigned*>(at_ws(ctx, WS_FILTER_MISC, 256, stream));  // word 0 = max|c|^2, as the sweep wants it
+    unsigned* misc = static_cast<unsigned*>(at_ws(ctx, WS_FILTER_MISC, 1024, stream));  // word 0 = max|c|^2, as the sweep wants it
     if (!img || !misc) return AT_E_NOMEM;
     AT_HIP(hipMemsetAsync(misc, 0, sizeof(unsigned), stream));
     hipLaunchKernelGGL(prep_centroids_f16_kernel, dim3(ng), dim3(WG), 0, stream, c, k, d, cperm, img, misc);
@@ -1237,7 +1332,7 @@ int at_filter_coarse(at_ctx* ctx, const float* x, int64_t n, int d, const float*
     unsigned char* img = static_cast<unsigned char*>(at_ws(ctx, WS_CENT_IMG16, group_bytes(d) * (size_t)ng, stream));
     unsigned char* img_m = static_cast<unsigned char*>(at_ws(ctx, WS_CENT_IMG16B, group_bytes(d) * (size_t)ngm, stream));
     int32_t* perm_m = static_cast<int32_t*>(at_ws(ctx, WS_IOTA, sizeof(int32_t) * (size_t)ngm * 32, stream));
-    unsigned* misc = static_cast<unsigned*>(at_ws(ctx, WS_FILTER_MISC, 256, stream));
+    unsigned* misc = static_cast<unsigned*>(at_ws(ctx, WS_FILTER_MISC, 1024, stream));
     if (!img || !img_m || !perm_m || !misc) return AT_E_NOMEM;
     ctx->img16_c = nullptr;
     hipLaunchKernelGGL(iota_pad_kernel, dim3((ngm * 32 + WG - 1) / WG), dim3(WG), 0, stream, perm_m, ng, ngm * 32);
@@ -1263,11 +1358,11 @@ int at_filter_coarse(at_ctx* ctx, const float* x, int64_t n, int d, const float*
     if (d == 128)
         hipLaunchKernelGGL((assign_f16filter_kernel<128, 2, true, false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, x,
                            (long)n, img, ng, no_order, no_bd, no_mask, ngw, misc, ta, tb, ra, rb, 1, 0,
-                           reinterpret_cast<long*>(ids), no_list, no_list, no_approx, fp);
+                           reinterpret_cast<long*>(ids), no_list, no_list, no_approx, fp, static_cast<uint4*>(nullptr), 0u);
     else
         hipLaunchKernelGGL((assign_f16filter_kernel<64, 4, true, false>), dim3((unsigned)((n + 127) / 128)), dim3(64), 0, stream, x,
                            (long)n, img, ng, no_order, no_bd, no_mask, ngw, misc, ta, tb, ra, rb, 1, 0,
-                           reinterpret_cast<long*>(ids), no_list, no_list, no_approx, fp);
+                           reinterpret_cast<long*>(ids), no_list, no_list, no_approx, fp, static_cast<uint4*>(nullptr), 0u);
     AT_LAUNCH_CHECK();
     return AT_OK;
 }

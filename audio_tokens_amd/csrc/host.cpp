@@ -42,6 +42,7 @@ const DebugField kDebugFields[] = {
     {"dmin_kernel", "AT_DMIN_KERNEL", &at_debug::dmin_kernel, 1},
     {"resample_simple", "AT_RESAMPLE_SIMPLE", &at_debug::resample_simple, 0},
     {"accum_buckets", "AT_ACCUM_BUCKETS", &at_debug::accum_buckets, 1},
+    {"filter_stats", "AT_FILTER_STATS", &at_debug::filter_stats, 0},
 };
 }  // namespace
 

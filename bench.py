@@ -179,9 +179,17 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     trace, be.assign_trace = be.assign_trace, None
-    f_rows, f_listed, f_ms, f_sweeps, f_tiles, f_refined = be.filter_stats(timing=True)   # timed steps only
+    f_rows, f_listed, f_ms, f_sweeps, _, _ = be.filter_stats(timing=True)   # timed steps only
+    # One extra, untimed step: the per-stage split, and -- with the counting switch on, which the product leaves off --
+    # the tiles / accumulators the sweeps computed.  The step is deterministic, so the timed steps computed the same.
+    be.debug_set("filter_stats", 1)
+    be.prune_stats(reset=True)
+    be.filter_stats(reset=True)
+    stage = pipe.run(wave_tr, wave_va, timing=True).stage_seconds
+    _, _, _, _, f_tiles, f_refined = be.filter_stats(timing=True)
+    f_tiles, f_refined = f_tiles * args.steps, f_refined * args.steps
     needed, total = be.prune_stats()
-    stage = pipe.run(wave_tr, wave_va, timing=True).stage_seconds  # one extra, untimed, per-stage split
+    be.debug_set("filter_stats", 0)
 
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")

@@ -73,10 +73,12 @@ def test_logmel_spectrogram_operator(be):
     assert np.array_equal(bits(allc[0].cpu().numpy()), bits(one[0].cpu().numpy()))
 
 
-def test_kmeans_pruned_path_matches_oracle(be, oracle):
+def test_kmeans_pruned_path_matches_oracle(be, oracle, switches):
     """A train() large enough to take the pruned / coarse-to-fine path (k >= 1024), cold start and
     warm start, against the oracle; and the same with pruning switched off."""
     from audio_tokens_amd.ops import Kmeans
+    switches(filter_stats=1)                                 # (the sweeps count what they skip only when asked to)
+    be.prune_stats(reset=True)
     rng = np.random.default_rng(9)
     cen = rng.standard_normal((2048, 64))
     x = (cen[rng.integers(0, 2048, 60000)] + 0.4 * rng.standard_normal((60000, 64))).astype(np.float32)
