@@ -125,6 +125,7 @@ struct at_ctx {
     const int32_t* img16_cperm;
     const unsigned* img16_misc;
     int img16_k, img16_d, img16_ng, img16_trusted;
+    int img16_misc_clean;   // the words behind max|c|^2 in img16_misc are still zero (nobody has swept since they were cleared)
 };
 
 int at_fail(int code, const char* fmt, ...);

@@ -1005,12 +1005,16 @@ __global__ void __launch_bounds__(WG) exact_rows_kernel(const float* __restrict_
 }
 
 // dmin[p][g] = a lower bound of min over the members m of group g of |c_p - c_m| (prune.hip uses it in
-// Elkan's test), from the same fp16-split products as the sweep: P(m) + |c_p|^2 - eps <= true squared
-// distance.  One wave = 64 centroids p (two 32-row tiles as the MFMA B operand) x GPW groups.
-constexpr int DMIN_GPW = 16;
+// Elkan's test), from the hi*hi product of the sweep's fp16 split alone: the hi*hi value P is within rho of the
+// three-term value (filter_rho) and that within eps of the truth (header), so P + |c_p|^2 - (eps + rho) <= the true
+// squared distance.  (Round 1 evaluated all three products here: 3x the MFMAs and twice the fragment bytes for a
+// bound that is 0.4 % tighter on unit rows; the table is rebuilt every Lloyd iteration on every rank.)
+// One wave = 64 centroids p (two 32-row tiles as the MFMA B operand) x GPW groups, the next group's fragments
+// fetched while the current one multiplies.
+constexpr int DMIN_GPW = 8;
 
 template <int D>
-__global__ void __launch_bounds__(64, 2)
+__global__ void __launch_bounds__(64, 4)
 group_min_dist_f16_kernel(const float* __restrict__ C, int k, const unsigned char* __restrict__ img, int ng,
                           const unsigned* __restrict__ misc, float eps_a, float eps_b, float* __restrict__ dmin) {
     constexpr int NS = D / 16;
@@ -1021,7 +1025,7 @@ group_min_dist_f16_kernel(const float* __restrict__ C, int k, const unsigned cha
     const float cnmax = __uint_as_float(misc[0]);
     const bool c_bad = !(cnmax < RANGE_SQ);
 
-    half8 xh[2][NS], xl[2][NS];
+    half8 xh[2][NS];
     float cnp[2], eps[2];
 #pragma unroll
     for (int b = 0; b < 2; b++) {
@@ -1035,40 +1039,27 @@ group_min_dist_f16_kernel(const float* __restrict__ C, int k, const unsigned cha
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 part = __builtin_fmaf(u[e], u[e], part);
-                const _Float16 hu = (_Float16)u[e];
-                xh[b][s][e] = hu;
-                xl[b][s][e] = (_Float16)(u[e] - (float)hu);
+                xh[b][s][e] = (_Float16)u[e];
                 part = __builtin_fmaf(v[e], v[e], part);
-                const _Float16 hv = (_Float16)v[e];
-                xh[b][s][4 + e] = hv;
-                xl[b][s][4 + e] = (_Float16)(v[e] - (float)hv);
+                xh[b][s][4 + e] = (_Float16)v[e];
             }
         }
         cnp[b] = part + __shfl_xor(part, 32);
         eps[b] = __builtin_fmaf(eps_a, cnp[b] * 1.001f + cnmax, eps_b);
     }
-    for (int g = g0; g < g0 + DMIN_GPW && g < ng; g++) {
+    auto load = [&](int g, half8 (&ah)[NS], f32x4 (&cn)[4]) {
         const unsigned char* base = img + (size_t)g * GB;
         const half8* fh = reinterpret_cast<const half8*>(base);
-        const half8* fl = reinterpret_cast<const half8*>(base + lo_off(D));
-        half8 ah[NS], al[NS];
 #pragma unroll
-        for (int s = 0; s < NS; s++) {
-            ah[s] = fh[s * 64 + lane];
-            al[s] = fl[s * 64 + lane];
-        }
-        f32x4 cn[4];
+        for (int s = 0; s < NS; s++) ah[s] = fh[s * 64 + lane];
         const float* cnq = reinterpret_cast<const float*>(base + misc_off(D));
 #pragma unroll
         for (int q = 0; q < 4; q++) cn[q] = *reinterpret_cast<const f32x4*>(cnq + 8 * q + 4 * h);
+    };
+    auto compute = [&](int g, const half8 (&ah)[NS], const f32x4 (&cn)[4]) {
 #pragma unroll
         for (int b = 0; b < 2; b++) {
             f32x16 a = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int s = 0; s < NS; s++) {
-                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], xh[b][s], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xl[b][s], a, 0, 0, 0);
-            }
 #pragma unroll
             for (int s = 0; s < NS; s++) a = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[b][s], a, 0, 0, 0);
             float P[16];
@@ -1084,6 +1075,17 @@ group_min_dist_f16_kernel(const float* __restrict__ C, int k, const unsigned cha
                 dmin[(size_t)p * ng + g] = lb;
             }
         }
+    };
+    const int g1 = g0 + DMIN_GPW < ng ? g0 + DMIN_GPW : ng;
+    half8 ahA[NS], ahB[NS];
+    f32x4 cnA[4], cnB[4];
+    if (g0 < g1) load(g0, ahA, cnA);
+    for (int g = g0; g < g1; g += 2) {
+        if (g + 1 < g1) load(g + 1, ahB, cnB);
+        compute(g, ahA, cnA);
+        if (g + 1 >= g1) break;
+        if (g + 2 < g1) load(g + 2, ahA, cnA);
+        compute(g + 1, ahB, cnB);
     }
 }
 
@@ -1146,8 +1148,13 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
     const bool reuse = ctx->img16_trusted && ctx->img16_c == c && ctx->img16_cperm == cperm && ctx->img16_k == k &&
                        ctx->img16_d == d && ctx->img16_ng == ng && misc == ctx->img16_misc;
     ctx->img16_trusted = 0;
+    const int misc_was_clean = ctx->img16_misc_clean;
+    ctx->img16_misc_clean = 0;
+    (void)misc_was_clean;
     if (reuse) {
-        AT_HIP(hipMemsetAsync(misc + 1, 0, 127 * sizeof(unsigned), stream));  // statistics, sub-list lengths
+        // statistics and sub-list lengths behind max|c|^2: at_group_min_dist_f16 cleared them with the same memset that
+        // cleared max|c|^2 (an odd-sized memset from misc + 1 costs two fill launches)
+        if (!misc_was_clean) AT_HIP(hipMemsetAsync(misc + 1, 0, 127 * sizeof(unsigned), stream));
     } else {
         ctx->img16_c = nullptr;
         AT_HIP(hipMemsetAsync(misc, 0, 128 * sizeof(unsigned), stream));  // max|c|^2, statistics, sub-list lengths
@@ -1280,17 +1287,20 @@ int at_group_min_dist_f16(at_ctx* ctx, const float* c, int k, int d, const int32
     unsigned char* img = static_cast<unsigned char*>(at_ws(ctx, WS_CENT_IMG16, group_bytes(d) * (size_t)ng, stream));
     unsigned* misc = static_cast<unsigned*>(at_ws(ctx, WS_FILTER_MISC, 1024, stream));  // word 0 = max|c|^2, as the sweep wants it
     if (!img || !misc) return AT_E_NOMEM;
-    AT_HIP(hipMemsetAsync(misc, 0, sizeof(unsigned), stream));
+    AT_HIP(hipMemsetAsync(misc, 0, 128 * sizeof(unsigned), stream));   // max|c|^2 and, for the sweep that follows, its counters
     hipLaunchKernelGGL(prep_centroids_f16_kernel, dim3(ng), dim3(WG), 0, stream, c, k, d, cperm, img, misc);
     AT_LAUNCH_CHECK();
     ctx->img16_c = c; ctx->img16_cperm = cperm; ctx->img16_k = k; ctx->img16_d = d; ctx->img16_ng = ng;
     ctx->img16_misc = misc;
+    ctx->img16_misc_clean = 1;
     // eps of the filter's budget (header of this file) without the contract's delta: tau = 2 delta + 2 eps
     float ta = 0.0f, tb = 0.0f;
     filter_tau(d, &ta, &tb);
     const double u = std::ldexp(1.0, -24);
-    const float eps_a = (float)(0.5 * ((double)ta - 2.0 * (2.0 * d + 8.0) * u * 1.01) * 1.001);
-    const float eps_b = 0.5f * tb * 1.001f;
+    float ra = 0.0f, rb = 0.0f;
+    filter_rho(d, &ra, &rb);     // the kernel keeps the hi*hi product only
+    const float eps_a = (float)(0.5 * ((double)ta - 2.0 * (2.0 * d + 8.0) * u * 1.01) * 1.001) + ra;
+    const float eps_b = 0.5f * tb * 1.001f + rb;
     const dim3 grid((unsigned)((k + 63) / 64), (unsigned)((ng + DMIN_GPW - 1) / DMIN_GPW));
     if (d == 64)
         hipLaunchKernelGGL(group_min_dist_f16_kernel<64>, grid, dim3(64), 0, stream, c, k, img, ng, misc, eps_a, eps_b, dmin);
@@ -1335,6 +1345,7 @@ int at_filter_coarse(at_ctx* ctx, const float* x, int64_t n, int d, const float*
     unsigned* misc = static_cast<unsigned*>(at_ws(ctx, WS_FILTER_MISC, 1024, stream));
     if (!img || !img_m || !perm_m || !misc) return AT_E_NOMEM;
     ctx->img16_c = nullptr;
+    ctx->img16_misc_clean = 0;
     hipLaunchKernelGGL(iota_pad_kernel, dim3((ngm * 32 + WG - 1) / WG), dim3(WG), 0, stream, perm_m, ng, ngm * 32);
     AT_HIP(hipMemsetAsync(misc, 0, 64 * sizeof(unsigned), stream));
     hipLaunchKernelGGL(prep_centroids_f16_kernel, dim3(ngm), dim3(WG), 0, stream, means, ng, d, perm_m, img_m,

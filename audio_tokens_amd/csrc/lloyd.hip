@@ -42,6 +42,15 @@ __global__ __launch_bounds__(WG) void split_clusters_kernel(int d, int k, long n
     __shared__ int n_empty;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
+    // the usual iteration has no empty cluster: one pass and one barrier settle that
+    {
+        bool any = false;
+        for (int c = t; c < k; c += WG) any |= hassign[c] == 0.0f;
+        if (!__syncthreads_or(any)) {
+            if (t == 0) *nsplit_out = 0;
+            return;
+        }
+    }
     // ordered list of the clusters that came out empty (a repair never empties or fills another one)
     if (t == 0) n_empty = 0;
     __syncthreads();
