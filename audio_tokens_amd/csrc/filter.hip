@@ -152,6 +152,7 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
     __shared__ float stash_tau[STASH ? NB : 1][64], stash_gbd[STASH ? NB : 1][64];
     __shared__ unsigned stash_row[STASH ? NB : 1][64], stash_hint[STASH ? NB : 1][64];
     const unsigned char* img_cur = img;  // the image the walk reads: the centroids', or first the group means'
+    bool means_walk = false;             // (guess generator) the walk under way is the one over the group means
     __shared__ half8 xl_lds[NB][D / 16][64];  // lo parts of the rows: only the rare refined tiles read them
 
     const int lane = threadIdx.x;
@@ -365,6 +366,7 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
                 cnt += __builtin_popcountll(bal);
             }
             img_cur = fp.means_img;
+            means_walk = true;
         } else {
             const long tile0 = pos0 / 32;
             for (int base = 0; base < ng; base += 64) {
@@ -457,22 +459,25 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
                 // guess generator (coarse passes): nobody has a running best worth screening against, so
                 // every tile gets all three products (a guess made from hi*hi alone is measurably worse and
                 // costs the exact pass more than it saves here), but only the best candidate is kept
-                if (!have_al) {
-                    const half8* fr = reinterpret_cast<const half8*>(img_cur + (size_t)g * GB + lo_off(D));
+                // (the walk over the group MEANS only picks which groups to search: hi*hi is all it needs)
+                if (!means_walk) {
+                    if (!have_al) {
+                        const half8* fr = reinterpret_cast<const half8*>(img_cur + (size_t)g * GB + lo_off(D));
 #pragma unroll
-                    for (int s = 0; s < NS; s++) al[s] = fr[s * 64 + lane];
-                    have_al = true;
-                }
-                n_ref += (unsigned)need0 + (unsigned)need1;
-#pragma unroll
-                for (int s = 0; s < NS; s++) {
-                    if (need0) {
-                        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], xh[t0][s], a0, 0, 0, 0);
-                        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xl_lds[t0][s][lane], a0, 0, 0, 0);
+                        for (int s = 0; s < NS; s++) al[s] = fr[s * 64 + lane];
+                        have_al = true;
                     }
-                    if (need1) {
-                        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], xh[t1][s], a1, 0, 0, 0);
-                        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xl_lds[t1][s][lane], a1, 0, 0, 0);
+                    n_ref += (unsigned)need0 + (unsigned)need1;
+#pragma unroll
+                    for (int s = 0; s < NS; s++) {
+                        if (need0) {
+                            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], xh[t0][s], a0, 0, 0, 0);
+                            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xl_lds[t0][s][lane], a0, 0, 0, 0);
+                        }
+                        if (need1) {
+                            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], xh[t1][s], a1, 0, 0, 0);
+                            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xl_lds[t1][s][lane], a1, 0, 0, 0);
+                        }
                     }
                 }
 #pragma unroll
@@ -585,6 +590,7 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
                 i1[b] = i2[b] = NONE;
             }
             img_cur = img;
+            means_walk = false;
             cnt = 0;
             for (int base = 0; base < ng; base += 64) {
                 const int g = base + lane;

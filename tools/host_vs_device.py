@@ -42,7 +42,7 @@ for name in dir(be):
     if callable(f) and not isinstance(f, type):
         try: setattr(be, name, wrap(name, f))
         except Exception: pass
-x = frames[:2097152].contiguous()
+x = frames[:int(os.environ.get('ROWS', '2097152'))].contiguous()
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
     torch.cuda.synchronize(); t0 = time.perf_counter()
