@@ -80,6 +80,7 @@ struct at_debug {
     int filter_wps2;      // AT_FILTER_WPS2      1 = two waves per SIMD in the Lloyd-sized filter sweeps
     int dmin_kernel;      // AT_DMIN_KERNEL      0 = fp32 vector-ALU kernel for the centroid-to-group bounds
     int resample_simple;  // AT_RESAMPLE_SIMPLE  1 = one-thread-per-sample resampler
+    int visit_bits;       // AT_VISIT_BITS       distance bits of the visiting-order key (0..8; default 8)
     int filter_stats;     // AT_FILTER_STATS     1 = the sweeps count accumulators / tiles for at_prune_stats, at_filter_stats
     int accum_buckets;    // AT_ACCUM_BUCKETS    0 = member lists by radix sort (the only form for k > 16 384)
 };

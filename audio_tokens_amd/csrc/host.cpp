@@ -43,6 +43,7 @@ const DebugField kDebugFields[] = {
     {"resample_simple", "AT_RESAMPLE_SIMPLE", &at_debug::resample_simple, 0},
     {"accum_buckets", "AT_ACCUM_BUCKETS", &at_debug::accum_buckets, 1},
     {"filter_stats", "AT_FILTER_STATS", &at_debug::filter_stats, 0},
+    {"visit_bits", "AT_VISIT_BITS", &at_debug::visit_bits, 8},
 };
 }  // namespace
 

@@ -85,21 +85,22 @@ __global__ void __launch_bounds__(WG) group_min_dist_kernel(const float* __restr
 __global__ void __launch_bounds__(WG) visit_keys_kernel(const long* __restrict__ ids,
                                                         const float* __restrict__ dis, long n, int k,
                                                         uint32_t* __restrict__ keys,
-                                                        uint32_t* __restrict__ vals) {
+                                                        uint32_t* __restrict__ vals, int dbits) {
     const long i = (long)blockIdx.x * WG + threadIdx.x;
     if (i >= n) return;
     const long c = ids[i];
     const bool ok = c >= 0 && c < k;
-    float r = dis ? sqrtf(fmaxf(dis[i], 0.0f)) * 127.0f : 0.0f;   // unit rows: r <= 2
-    r = fminf(r, 255.0f);
-    keys[i] = ((ok ? (uint32_t)c : (uint32_t)k) << 8) | (uint32_t)r;
+    const float top = (float)((1u << dbits) - 1u);
+    float r = dis ? sqrtf(fmaxf(dis[i], 0.0f)) * (0.5f * top) : 0.0f;   // unit rows: r <= 2
+    r = fminf(r, top);
+    keys[i] = ((ok ? (uint32_t)c : (uint32_t)k) << dbits) | (uint32_t)r;
     vals[i] = (uint32_t)i;
 }
 
 __global__ void __launch_bounds__(WG) key_to_hint_kernel(const uint32_t* __restrict__ keys, long n,
-                                                         uint32_t* __restrict__ hint_sorted) {
+                                                         uint32_t* __restrict__ hint_sorted, int dbits) {
     const long i = (long)blockIdx.x * WG + threadIdx.x;
-    if (i < n) hint_sorted[i] = keys[i] >> 8;
+    if (i < n) hint_sorted[i] = keys[i] >> dbits;
 }
 
 __global__ void __launch_bounds__(WG) max_sqnorm_kernel(const float* __restrict__ C, int k, int d,
@@ -412,12 +413,18 @@ int at_visit_order_f32(at_ctx* ctx, const int64_t* ids, const float* dis, int64_
     uint32_t* vals_a = static_cast<uint32_t*>(at_ws(ctx, WS_VISIT_VALS_A, (size_t)n * 4, stream));
     uint32_t* vals_b = static_cast<uint32_t*>(at_ws(ctx, WS_VISIT_VALS_B, (size_t)n * 4, stream));
     if (!keys_a || !keys_b || !vals_a || !vals_b) return AT_E_NOMEM;
+    // key = cluster | distance in `dbits` bits (switch visit_bits, default 8: measured 2.07 / 1.86 / 1.52 / 1.46 ms per
+    // Lloyd iteration at 0 / 2 / 5 / 8 bits on bench-like rows, no further gain at 10 or 12)
+    unsigned cbits = 1;
+    while ((1u << cbits) <= (unsigned)k) cbits++;
+    int dbits = ctx->dbg.visit_bits;
+    if (dbits < 0) dbits = 0;
+    if (dbits > 12) dbits = 12;
+    if ((int)cbits + dbits > 32) dbits = 32 - (int)cbits;
     hipLaunchKernelGGL(visit_keys_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, stream,
-                       reinterpret_cast<const long*>(ids), dis, (long)n, k, keys_a, vals_a);
+                       reinterpret_cast<const long*>(ids), dis, (long)n, k, keys_a, vals_a, dbits);
     AT_LAUNCH_CHECK();
-    unsigned bits = 1;
-    while ((1u << bits) <= (unsigned)k) bits++;
-    bits += 8;
+    const unsigned bits = cbits + (unsigned)dbits;
     rocprim::double_buffer<uint32_t> kb(keys_a, keys_b);
     rocprim::double_buffer<uint32_t> vb(vals_a, vals_b);
     size_t tmp_bytes = 0;
@@ -427,7 +434,7 @@ int at_visit_order_f32(at_ctx* ctx, const int64_t* ids, const float* dis, int64_
     AT_HIP(rocprim::radix_sort_pairs<at_radix_config>(tmp, tmp_bytes, kb, vb, (size_t)n, 0, bits, stream));
     AT_HIP(hipMemcpyAsync(order_out, vb.current(), sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream));
     hipLaunchKernelGGL(key_to_hint_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, stream, kb.current(),
-                       (long)n, hint_sorted_out);
+                       (long)n, hint_sorted_out, dbits);
     AT_LAUNCH_CHECK();
     return AT_OK;
 }

@@ -7,7 +7,7 @@
  *                                 initialised from the AT_* environment variables once, in at_create, and never read
  *                                 from the environment again; names:
  *                                   assign_variant filter_fused filter_sync prune_kernel prune_nb filter_screen
- *                                   filter_nb filter_wps2 dmin_kernel resample_simple accum_buckets filter_stats
+ *                                   filter_nb filter_wps2 dmin_kernel resample_simple accum_buckets filter_stats visit_bits
  *                                 (filter_stats = 1 makes the fp16-split sweeps count for the two calls below: one record
  *                                 per workgroup and a small reduction kernel behind every sweep; off by default)
  *   at_prune_stats                running totals over the context's exact pruned sweeps: 32x32 accumulators computed /

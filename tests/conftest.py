@@ -48,7 +48,7 @@ def be():
 
 _NATIVE_DEFAULTS = {"assign_variant": 0, "filter_fused": 1, "filter_sync": 0, "prune_kernel": 1, "prune_nb": 0,
                     "filter_screen": 1, "filter_nb": 0, "filter_wps2": 0, "dmin_kernel": 1, "resample_simple": 0,
-                    "accum_buckets": 1, "filter_stats": 0}
+                    "accum_buckets": 1, "filter_stats": 0, "visit_bits": 8}
 
 
 @pytest.fixture()
