@@ -1019,8 +1019,8 @@ __global__ void __launch_bounds__(WG) exact_rows_kernel(const float* __restrict_
 // fetched while the current one multiplies.
 constexpr int DMIN_GPW = 8;
 
-template <int D>
-__global__ void __launch_bounds__(64, 4)
+template <int D, bool THREE>
+__global__ void __launch_bounds__(64, THREE ? 2 : 4)
 group_min_dist_f16_kernel(const float* __restrict__ C, int k, const unsigned char* __restrict__ img, int ng,
                           const unsigned* __restrict__ misc, float eps_a, float eps_b, float* __restrict__ dmin) {
     constexpr int NS = D / 16;
@@ -1031,7 +1031,7 @@ group_min_dist_f16_kernel(const float* __restrict__ C, int k, const unsigned cha
     const float cnmax = __uint_as_float(misc[0]);
     const bool c_bad = !(cnmax < RANGE_SQ);
 
-    half8 xh[2][NS];
+    half8 xh[2][NS], xl[2][THREE ? NS : 1];
     float cnp[2], eps[2];
 #pragma unroll
     for (int b = 0; b < 2; b++) {
@@ -1045,9 +1045,15 @@ group_min_dist_f16_kernel(const float* __restrict__ C, int k, const unsigned cha
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 part = __builtin_fmaf(u[e], u[e], part);
-                xh[b][s][e] = (_Float16)u[e];
+                const _Float16 hu = (_Float16)u[e];
+                xh[b][s][e] = hu;
                 part = __builtin_fmaf(v[e], v[e], part);
-                xh[b][s][4 + e] = (_Float16)v[e];
+                const _Float16 hv = (_Float16)v[e];
+                xh[b][s][4 + e] = hv;
+                if constexpr (THREE) {
+                    xl[b][s][e] = (_Float16)(u[e] - (float)hu);
+                    xl[b][s][4 + e] = (_Float16)(v[e] - (float)hv);
+                }
             }
         }
         cnp[b] = part + __shfl_xor(part, 32);
@@ -1066,6 +1072,14 @@ group_min_dist_f16_kernel(const float* __restrict__ C, int k, const unsigned cha
 #pragma unroll
         for (int b = 0; b < 2; b++) {
             f32x16 a = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if constexpr (THREE) {   // (switch dmin_kernel = 2: all three products, the tighter eps)
+                const half8* fl = reinterpret_cast<const half8*>(img + (size_t)g * GB + lo_off(D));
+#pragma unroll
+                for (int s = 0; s < NS; s++) {
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[s * 64 + lane], xh[b][s], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xl[b][s], a, 0, 0, 0);
+                }
+            }
 #pragma unroll
             for (int s = 0; s < NS; s++) a = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[b][s], a, 0, 0, 0);
             float P[16];
@@ -1303,15 +1317,20 @@ int at_group_min_dist_f16(at_ctx* ctx, const float* c, int k, int d, const int32
     float ta = 0.0f, tb = 0.0f;
     filter_tau(d, &ta, &tb);
     const double u = std::ldexp(1.0, -24);
+    const bool three = ctx->dbg.dmin_kernel == 2;
     float ra = 0.0f, rb = 0.0f;
-    filter_rho(d, &ra, &rb);     // the kernel keeps the hi*hi product only
+    if (!three) filter_rho(d, &ra, &rb);     // the kernel keeps the hi*hi product only
     const float eps_a = (float)(0.5 * ((double)ta - 2.0 * (2.0 * d + 8.0) * u * 1.01) * 1.001) + ra;
     const float eps_b = 0.5f * tb * 1.001f + rb;
     const dim3 grid((unsigned)((k + 63) / 64), (unsigned)((ng + DMIN_GPW - 1) / DMIN_GPW));
-    if (d == 64)
-        hipLaunchKernelGGL(group_min_dist_f16_kernel<64>, grid, dim3(64), 0, stream, c, k, img, ng, misc, eps_a, eps_b, dmin);
+    if (d == 64 && three)
+        hipLaunchKernelGGL((group_min_dist_f16_kernel<64, true>), grid, dim3(64), 0, stream, c, k, img, ng, misc, eps_a, eps_b, dmin);
+    else if (d == 64)
+        hipLaunchKernelGGL((group_min_dist_f16_kernel<64, false>), grid, dim3(64), 0, stream, c, k, img, ng, misc, eps_a, eps_b, dmin);
+    else if (three)
+        hipLaunchKernelGGL((group_min_dist_f16_kernel<128, true>), grid, dim3(64), 0, stream, c, k, img, ng, misc, eps_a, eps_b, dmin);
     else
-        hipLaunchKernelGGL(group_min_dist_f16_kernel<128>, grid, dim3(64), 0, stream, c, k, img, ng, misc, eps_a, eps_b, dmin);
+        hipLaunchKernelGGL((group_min_dist_f16_kernel<128, false>), grid, dim3(64), 0, stream, c, k, img, ng, misc, eps_a, eps_b, dmin);
     AT_LAUNCH_CHECK();
     return AT_OK;
 }

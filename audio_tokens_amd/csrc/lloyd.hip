@@ -23,7 +23,10 @@ constexpr int WG = 256;
 // so a scan still empty-handed after 64 cycles (chance < 1e-27) has no donor to find: the kernel reports -1
 // instead of spinning (every wave reaches this exit).
 constexpr long SPLIT_CYCLES = 64;
-constexpr int SPLIT_ROUND = 4 * WG;   // candidates tested per step while the draws come from the context's cache
+constexpr int SPLIT_BLOCKS = 16;
+constexpr int SPLIT_ROUND = SPLIT_BLOCKS * WG;   // candidates tested per step while the draws come from the context's cache
+// (a repair scans 1 / mean(p) = k candidates on average and a step costs one trip to L2 and two barriers whatever its
+// width: 16 blocks instead of round 2's first 4 took the 160 repairs of a cold first iteration from 2.1-4.2 ms to a quarter)
 
 // RandomGenerator::rand_float: mt() / float(mt.max()) -- float(2^32 - 1) is 2^32
 __device__ __forceinline__ float rand_float_of(uint32_t raw) { return __uint2float_rn(raw) * 2.3283064365386963e-10f; }
@@ -90,28 +93,28 @@ __global__ __launch_bounds__(WG) void split_clusters_kernel(int d, int k, long n
         long left = SPLIT_CYCLES * k + 1024;
         while (left > 0 && donor < 0) {
             if (pos + SPLIT_ROUND <= raw_n) {
-                // four blocks of 256 candidates at once, draws straight from the resident stream
-                int firsts[4];
+                // SPLIT_BLOCKS blocks of 256 candidates at once, draws straight from the resident stream; candidate j of
+                // the step is tested by thread j % 256 as its (j / 256)-th, so a wave's earliest acceptance is in its
+                // first block with any, and the step's earliest is the smallest of the four waves'
+                uint32_t draw[SPLIT_BLOCKS];
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
+                for (int i = 0; i < SPLIT_BLOCKS; i++) draw[i] = raw[pos + i * WG + t];
+                int mine = INT_MAX;
+#pragma unroll
+                for (int i = 0; i < SPLIT_BLOCKS; i++) {
                     const int j = i * WG + t;
                     int cj = cj0 + j;
                     cj -= (cj / k) * k;
                     const float pc = p_lds ? pl[cj] : prob(cj);
-                    const bool acc = rand_float_of(raw[pos + j]) < pc;
+                    const bool acc = rand_float_of(draw[i]) < pc;
                     const unsigned long long b = __ballot(acc);
-                    firsts[i] = b ? i * WG + wave * 64 + (__ffsll((long long)b) - 1) : INT_MAX;
+                    if (b && mine == INT_MAX) mine = i * WG + wave * 64 + (__ffsll((long long)b) - 1);
                 }
-                if (lane == 0) {
-#pragma unroll
-                    for (int i = 0; i < 4; i++) wave_val[i][wave] = firsts[i];
-                }
+                if (lane == 0) wave_val[0][wave] = mine;
                 __syncthreads();
                 int first = INT_MAX;
 #pragma unroll
-                for (int i = 0; i < 4; i++)
-#pragma unroll
-                    for (int w = 0; w < WG / 64; w++) first = min(first, wave_val[i][w]);
+                for (int w = 0; w < WG / 64; w++) first = min(first, wave_val[0][w]);
                 __syncthreads();
                 if (first != INT_MAX) {
                     donor = (int)((cj0 + (long)first) % k);
