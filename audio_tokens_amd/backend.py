@@ -164,6 +164,27 @@ class HipBackend(HostHelpers):
             t = t.to(dtype)
         return t.to(self.device, non_blocking=False)
 
+    def from_host_async(self, a, dtype=None) -> torch.Tensor:
+        """from_host through a pinned staging buffer: the copy is queued on the current stream and the caller goes
+        on (a pageable copy would first wait for everything queued before it).  For small tables."""
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        if dtype is not None:
+            t = t.to(dtype)
+        key = ("h2d", tuple(t.shape), t.dtype)
+        pool = self.__dict__.setdefault("_pinned_pool", {})
+        slot = pool.get(key)
+        if slot is None:
+            slot = pool[key] = [[torch.empty(t.shape, dtype=t.dtype).pin_memory() for _ in range(4)], 0, [None] * 4]
+        i = slot[1] % 4
+        if slot[2][i] is not None:
+            slot[2][i].synchronize()          # (the copy that last used this staging buffer, four uploads ago)
+        h = slot[0][i]
+        slot[1] += 1
+        h.copy_(t)
+        out = h.to(self.device, non_blocking=True)
+        slot[2][i] = self.record_event()
+        return out
+
     def to_host(self, t: torch.Tensor) -> np.ndarray:
         return t.detach().cpu().numpy()
 
@@ -173,6 +194,12 @@ class HipBackend(HostHelpers):
 
     def synchronize(self) -> None:
         torch.cuda.current_stream(self.device).synchronize()
+
+    def record_event_timed(self):
+        """record_event with timing: `a.elapsed_time(b)` between two of them once both have completed."""
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream(self.device))
+        return ev
 
     def record_event(self):
         """Event on the current stream; `.synchronize()` on it waits for the work queued so far only."""

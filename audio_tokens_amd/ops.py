@@ -18,6 +18,8 @@ rows and the per-cluster partial sums/counts are exchanged once per iteration.
 """
 from __future__ import annotations
 
+import collections
+import os
 import sys
 import time
 from collections import OrderedDict
@@ -343,6 +345,7 @@ class Kmeans:
             # The spatial grouping only decides how much the exact sweep can skip.  A warm start begins with
             # the grouping the previous train() ended with while the host regroups the new initial centroids
             # beside the first iterations; a cold start groups its initial centroids before it can begin.
+            upload = getattr(be, "from_host_async", be.from_host)   # (the small table goes up without draining the stream)
             cached = getattr(self, "_cperm_cache", None)
             if init_centroids is not None and cached is not None and cached[0] == (k, d):
                 cperm = cached[1]
@@ -356,17 +359,33 @@ class Kmeans:
             gnbr = None
         # a last regrouping near the end: the next warm start and the tokeniser's index begin with it
         late_regroup = niter - 6 if niter >= 10 else -1
+        # The host queues an iteration several times faster than the device runs it.  Left alone it would be a whole
+        # training ahead, and a regrouping -- which needs the device to have reached the centroids it groups, plus
+        # ~3 ms of host work -- would arrive after the host had queued every iteration that could have used it.  So
+        # the host stays at most three iterations ahead (waiting on an event three iterations old: the device always
+        # has queued work), measures the device's iteration time from those events, and submits the late regrouping
+        # early enough to be finished when the last iteration is (short iterations: a shard of an N-GPU run).
+        paced = collections.deque()
+        iter_ms = None
+        last_done = None
+        timed_events = hasattr(be, "record_event_timed")
+
+        def late_due(it):
+            if late_regroup < 0 or it < niter // 2:
+                return False
+            return it >= late_regroup or (iter_ms is not None and (niter - it) * iter_ms <= 4.5)
 
         def pruned_assign(it):
             """Queues iteration `it`'s exact search over the current centroids -> (ids, dis)."""
             nonlocal cperm, regrouping, regrouping_is_late, gnbr
             if regrouping is not None and regrouping.done():
-                cperm = be.from_host(regrouping.result())
+                cperm = upload(regrouping.result())
                 regrouping = None
-            elif regrouping is None and ((it == 2 and init_centroids is None) or it == late_regroup):
-                # cold start: regroup once the centroids have settled (taken up when the host is done)
+            elif (it == 2 and init_centroids is None and regrouping is None) or (late_due(it) and not regrouping_is_late):
+                # cold start: regroup once the centroids have settled (taken up when the host is done); near the end:
+                # for the next warm start and the tokeniser (replaces one still under way: these centroids are newer)
+                regrouping_is_late = late_due(it)
                 regrouping = regroup_beside(cent)
-                regrouping_is_late = it == late_regroup
             dmin = be.group_min_dist(cent, cperm)
             if ids is None:   # no previous assignment yet: coarse-to-fine exact search
                 gnbr = be.group_neighbours(be.group_means(cent, cperm), 8)
@@ -416,6 +435,14 @@ class Kmeans:
                 be.lloyd_stats(hassign, parts, k, d, stats_dev[it])
             be.split_clusters_device(hassign, cent, ns, nsplit_dev[it:it + 1])
             tp = lap("exchange+finalize+split", tp)
+            if prune and timed_events:
+                paced.append(be.record_event_timed())
+                if len(paced) > 3:
+                    done = paced.popleft()
+                    done.synchronize()
+                    if last_done is not None:
+                        iter_ms = last_done.elapsed_time(done)
+                    last_done = done
         self._last_assign = ids
         self._stats_pending = (stats_dev[:niter], nsplit_dev[:niter], t0)
         if self.verbose:   # faiss' per-iteration lines, printed once the iterations are through (no wait inside the loop)
@@ -423,9 +450,8 @@ class Kmeans:
                 print(f"  Iteration {it} ({st['time']:.2f} s, search {st['time_search']:.2f} s): "
                       f"objective={st['obj']:g} imbalance={st['imbalance_factor']:.3f} nsplit={st['nsplit']}", flush=True)
         if prune:
-            # (the late one was submitted several iterations ago: done, or about to be)
             if regrouping is not None and (regrouping.done() or regrouping_is_late):
-                cperm = be.from_host(regrouping.result())
+                cperm = upload(regrouping.result())     # (submitted early enough to be done, or about to be)
             self._cperm_cache = ((k, d), cperm)
             self._grouping_of_result = cperm
         return self._finish(cent, sync)
