@@ -69,6 +69,7 @@ SIGNATURES = {
     "at_sum_parts_f32": (_i32, [_vp, _vp, _i64, _i32, _i64, _vp, _vp]),
     "at_sum_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "at_any_nonfinite_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "at_logmel_nonfinite_take": (_i32, [_vp, _vp, _vp]),
     "at_centroid_accum_defer": (_i32, [_vp, _i32]),
     "at_centroid_accum_join": (_i32, [_vp, _vp]),
     "at_token_histogram_i64": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),

@@ -664,6 +664,15 @@ class HipBackend(HostHelpers):
                                                      self._stream()))
         return flag
 
+    def logmel_nonfinite_take(self) -> torch.Tensor:
+        """Device int32 [1]: 1 if a unit-row pass of logmel(..., l2norm=True) since the last call met a frame whose
+        squared norm is not finite (a NaN / Inf in it, or squares that overflow: confirm with any_nonfinite).  Clears
+        the context's flag.  No synchronisation, and no second read of the frames."""
+        flag = self.empty((1,), torch.int32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_logmel_nonfinite_take(self.ctx.handle, _ptr(flag), self._stream()))
+        return flag
+
     def any_nonfinite(self, v) -> bool:
         return bool(self.nonfinite_flag(v).item())
 

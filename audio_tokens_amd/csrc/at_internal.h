@@ -51,6 +51,7 @@ enum at_ws_slot {
     WS_LONG_LATE,      // centroid_accum: long clusters left to the pass behind the sort
     WS_BUCKETS,        // centroid_accum bucket path: counts, cursors, the list of long clusters
     WS_LOGMEL_ANY,     // log-mel, general n_fft: window, twiddles, banded filterbank
+    WS_ROW_FLAG,       // one int: a unit-row pass of at_logmel_f32 met a row whose squared norm is not finite
     WS_FILTER_BLKSTATS, // fp16-split filter: one statistics record per workgroup of a sweep (switch filter_stats)
     WS_NSLOTS
 };
@@ -203,3 +204,8 @@ int at_filter_resolve_pending(at_ctx* ctx, bool wait_all);
 int at_filter_use_slot_events(at_ctx* ctx, int slot);
 
 static inline bool at_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// unit rows with a verdict: *bad (device int, may be null) is set when a row's norm is not finite (l2norm.hip)
+int at_l2norm_rows_flagged(at_ctx* ctx, const float* x, int64_t n, int d, float* y, int* bad, hipStream_t stream);
+int* at_row_flag(at_ctx* ctx, hipStream_t stream);   // the context's flag word (WS_ROW_FLAG), cleared when first allocated
+

@@ -18,8 +18,9 @@ namespace {
 
 constexpr int WG = 256;
 
+// bad (optional): set to 1 when a row's norm is not finite, i.e. when the row holds a NaN or Inf (or its squares overflow)
 __global__ void __launch_bounds__(WG) l2norm_rows_kernel(const float* __restrict__ x, long n, int d,
-                                                         int rows_per_block, float* __restrict__ y) {
+                                                         int rows_per_block, float* __restrict__ y, int* __restrict__ bad) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // R*(d+1) floats + R floats
     const int R = rows_per_block;
     const int pitch = d + 1;
@@ -35,6 +36,7 @@ __global__ void __launch_bounds__(WG) l2norm_rows_kernel(const float* __restrict
     __syncthreads();
     for (int r = threadIdx.x; r < rows; r += WG) {
         den[r] = l2n::row_denominator(sm + (size_t)r * pitch, d, 1);
+        if (bad && !(den[r] < __builtin_inff())) atomicOr(bad, 1);
     }
     __syncthreads();
     float* dst = y + row0 * d;
@@ -91,9 +93,37 @@ extern "C" int at_minmax_scale_clips_f32(at_ctx* ctx, float* x, int64_t n_clips,
     return AT_OK;
 }
 
+int* at_row_flag(at_ctx* ctx, hipStream_t stream) {
+    const bool fresh = ctx->ws[WS_ROW_FLAG] == nullptr;
+    int* f = static_cast<int*>(at_ws(ctx, WS_ROW_FLAG, 16, stream));
+    if (f && fresh && hipMemsetAsync(f, 0, 16, stream) != hipSuccess) return nullptr;
+    return f;
+}
+
+namespace {
+__global__ void row_flag_take_kernel(int* __restrict__ flag, int32_t* __restrict__ out) {
+    *out = *flag != 0;
+    *flag = 0;
+}
+}  // namespace
+
+extern "C" int at_logmel_nonfinite_take(at_ctx* ctx, int32_t* flag_out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AT_REQUIRE(ctx && flag_out, "at_logmel_nonfinite_take: null pointer");
+    AT_HIP(hipSetDevice(ctx->device));
+    int* f = at_row_flag(ctx, stream);
+    if (!f) return AT_E_NOMEM;
+    hipLaunchKernelGGL(row_flag_take_kernel, dim3(1), dim3(1), 0, stream, f, flag_out);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+}
+
 extern "C" int at_l2norm_rows_f32(at_ctx* ctx, const float* x, int64_t n, int d, float* y,
                                   void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+    return at_l2norm_rows_flagged(ctx, x, n, d, y, nullptr, static_cast<hipStream_t>(stream_));
+}
+
+int at_l2norm_rows_flagged(at_ctx* ctx, const float* x, int64_t n, int d, float* y, int* bad, hipStream_t stream) {
     AT_REQUIRE(ctx, "at_l2norm_rows_f32: ctx is null");
     AT_REQUIRE(n >= 0 && d > 0, "at_l2norm_rows_f32: bad sizes");
     if (n == 0) return AT_OK;
@@ -112,7 +142,7 @@ extern "C" int at_l2norm_rows_f32(at_ctx* ctx, const float* x, int64_t n, int d,
     }
     const long blocks = (n + R - 1) / R;
     hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)blocks), dim3(WG), lds, stream, x, (long)n, d,
-                       R, y);
+                       R, y, bad);
     AT_LAUNCH_CHECK();
     return AT_OK;
 }

@@ -52,6 +52,7 @@ struct LogmelParams {
     int fb_quads;           // bands padded to 4-aligned quads of bins (16-byte reads) or stored as they are
     float* out;
     int frame_major, fuse_l2norm;
+    int* bad;               // set to 1 when a frame's squared norm is not finite (fused unit rows only)
 };
 
 // PF: the next block's samples are prefetched through registers (needs a block of at most PREFETCH_REGS x WG x 4
@@ -184,7 +185,7 @@ __global__ void __launch_bounds__(WG, 2) logmel_kernel(LogmelParams p) {
                     // rounded log10 of 1e-10f gives; the device log10f is 1 ulp off there)
                     // (v_log_f32 is within an ulp of log2 on normal inputs -- s > 1e-10 here --: 1.2e-5 dB at most, a
                     // quarter of what the stated tolerance leaves; the library log10f costs twenty instructions)
-                    ostage[f * opitch + m] = s > 1e-10f ? 3.0102999566398120f * __builtin_amdgcn_logf(s) : -100.0f;
+                    ostage[f * opitch + m] = !(s <= 1e-10f) ? 3.0102999566398120f * __builtin_amdgcn_logf(s) : -100.0f;   // (a NaN power stays NaN, as torch.clamp leaves it)
                 }
             }
         }
@@ -198,7 +199,10 @@ __global__ void __launch_bounds__(WG, 2) logmel_kernel(LogmelParams p) {
                 const int f = tid >> 3;
                 if (f < nf) {
                     const float ss = l2n::pairwise_sumsq_8lanes(ostage + f * opitch, p.n_mels, tid & 7);
-                    if ((tid & 7) == 0) den[f] = __builtin_sqrtf(ss) + 1e-10f;
+                    if ((tid & 7) == 0) {
+                        den[f] = __builtin_sqrtf(ss) + 1e-10f;
+                        if (!(ss < __builtin_inff())) atomicOr(p.bad, 1);   // a NaN / Inf in the frame (faiss' input check, for free)
+                    }
                 }
                 __syncthreads();
             }
@@ -368,7 +372,11 @@ extern "C" int at_logmel_f32(at_ctx* ctx, const float* wave, int64_t n_clips, in
         int rc = at_logmel_any(ctx, wave, n_clips, L, wave_stride, sample_rate, n_fft, hop, n_mels, fb_or_null, out,
                                layout == AT_LAYOUT_FRAME_MAJOR, stream);
         if (rc) return rc;
-        if (fuse_l2norm) return at_l2norm_rows_f32(ctx, out, n_clips * at_num_frames(L, hop), n_mels, out, stream_);
+        if (fuse_l2norm) {
+            int* bad = at_row_flag(ctx, stream);
+            if (!bad) return AT_E_NOMEM;
+            return at_l2norm_rows_flagged(ctx, out, n_clips * at_num_frames(L, hop), n_mels, out, bad, stream);
+        }
         return AT_OK;
     }
 
@@ -384,6 +392,8 @@ extern "C" int at_logmel_f32(at_ctx* ctx, const float* wave, int64_t n_clips, in
     // other widths get the standalone kernel behind this one, in place
     const bool fuse_here = fuse_l2norm && n_mels >= 8 && n_mels <= 128;
     p.out = out; p.frame_major = layout == AT_LAYOUT_FRAME_MAJOR; p.fuse_l2norm = fuse_here;
+    p.bad = fuse_l2norm ? at_row_flag(ctx, stream) : nullptr;
+    if (fuse_l2norm && !p.bad) return AT_E_NOMEM;
     // the banded filterbank rides in LDS too unless a dense user filterbank makes it too big
     const size_t fb_ints = (((size_t)3 * n_mels + 3) & ~(size_t)3) + p.fb_nw;
     p.fb_lds = fb_ints * 4 <= 14 * 1024;
@@ -413,6 +423,6 @@ extern "C" int at_logmel_f32(at_ctx* ctx, const float* wave, int64_t n_clips, in
     if (pf) hipLaunchKernelGGL(logmel_kernel<true>, dim3((unsigned)grid), dim3(WG), lds, stream, p);
     else hipLaunchKernelGGL(logmel_kernel<false>, dim3((unsigned)grid), dim3(WG), lds, stream, p);
     AT_LAUNCH_CHECK();
-    if (fuse_l2norm && !fuse_here) return at_l2norm_rows_f32(ctx, out, n_clips * T, n_mels, out, stream_);
+    if (fuse_l2norm && !fuse_here) return at_l2norm_rows_flagged(ctx, out, n_clips * T, n_mels, out, p.bad, stream);
     return AT_OK;
 }

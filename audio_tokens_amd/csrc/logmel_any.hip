@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(WG) logmel_any_kernel(AnyParams p) {
             const int st = p.fb_start[m], ln = p.fb_len[m];
             float acc = 0.0f;
             for (int q = 0; q < ln; q++) acc = __builtin_fmaf(pw[st + q], wt[q], acc);
-            const float db = acc > 1e-10f ? 10.0f * log10f(acc) : -100.0f;
+            const float db = !(acc <= 1e-10f) ? 10.0f * log10f(acc) : -100.0f;   // (a NaN power stays NaN, as torch.clamp leaves it)
             if (p.frame_major) p.out[g * p.n_mels + m] = db;
             else p.out[(clip * p.n_mels + m) * p.T + t] = db;
         }

@@ -22,6 +22,7 @@ kernels; frames exist only for the k-means batch being trained and are recompute
 """
 from __future__ import annotations
 
+import os
 import time
 from dataclasses import dataclass, field
 
@@ -78,7 +79,12 @@ class DevicePipeline:
         secs = {}
 
         t0 = time.perf_counter()
+        take_flag = hasattr(be, "logmel_nonfinite_take")
+        if take_flag:
+            be.logmel_nonfinite_take()                 # (whatever earlier log-mel passes of this context left behind)
         frames_tr, T = self._frames(be._f32(wave_train))
+        # faiss' input check (Clustering::train) on the training frames, from the unit-row pass that wrote them
+        bad = be.logmel_nonfinite_take() if take_flag else None
         frames_va = None
         if wave_val is not None and wave_val.shape[0] > 0:
             frames_va, _ = self._frames(be._f32(wave_val))
@@ -93,7 +99,8 @@ class DevicePipeline:
         n_clips = wave_train.shape[0]
         per_rank = max(1, self.clustering_batch_size // self.world)
         pending = []
-        bad = be.nonfinite_flag(frames_tr)     # faiss' input check (Clustering::train), once for all batches
+        if bad is None:
+            bad = be.nonfinite_flag(frames_tr)     # faiss' input check (Clustering::train), once for all batches
         for b, c0 in enumerate(range(0, n_clips, per_rank)):
             c1 = min(n_clips, c0 + per_rank)
             x = frames_tr[c0 * T:c1 * T]
@@ -116,13 +123,18 @@ class DevicePipeline:
         sync(); secs["tokenize"] = time.perf_counter() - t0
 
         # the only host round trips of the pass, behind everything that was queued
-        if self.world > 1:   # (every rank must take the same decision, or the others would wait in the next collective)
-            import torch.distributed as dist
-            flag = bad.cpu() if dist.get_backend(self.process_group) == "gloo" else bad
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.process_group)
-            bad = flag
-        if bool(bad.item()):
-            raise RuntimeError("Error: 'std::isfinite(x_in[i])' failed: input contains NaN's or Inf's")
+        def over_ranks(flag):   # (every rank must take the same decision, or the others would wait in the next collective)
+            if self.world > 1:
+                import torch.distributed as dist
+                flag = flag.cpu() if dist.get_backend(self.process_group) == "gloo" else flag
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.process_group)
+            return bool(flag.item())
+
+        if over_ranks(bad):
+            # the unit-row pass flags a frame whose squared norm is not finite; squares that overflow look the same, so
+            # the verdict is confirmed by the scan it replaced (an error path: never on the timed one)
+            if not take_flag or over_ranks(be.nonfinite_flag(frames_tr)):
+                raise RuntimeError("Error: 'std::isfinite(x_in[i])' failed: input contains NaN's or Inf's")
         stats = [km._read_stats(*p) for p in pending if p is not None]
         return PipelineResult(centroids, tok_tr, tok_va, T, secs, stats)
 

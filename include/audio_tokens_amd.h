@@ -264,6 +264,14 @@ int at_sum_f32(at_ctx* ctx, const float* v, int64_t n, double* out, void* stream
 /* 1 if any of v[0..n) is NaN/Inf else 0, written to *flag (DEVICE int32). */
 int at_any_nonfinite_f32(at_ctx* ctx, const float* v, int64_t n, int32_t* flag, void* stream);
 
+/* The same verdict for the unit rows at_logmel_f32(..., fuse_l2norm = 1) has written since the last call, without
+ * reading them again: the unit-row pass sets a flag in the context when a row's squared norm is not finite (a NaN or
+ * Inf in the row; also squares that overflow, so a caller confirms a raised flag with at_any_nonfinite_f32).  Writes
+ * 0 / 1 to *flag (DEVICE int32) and clears the context's flag, in stream order.  Replaces the scan faiss makes of
+ * its training input (Clustering::train: FAISS_THROW_IF_NOT_MSG(std::isfinite(x_in[i]), ...), reached from
+ * processors/cluster_creator.py:54-56) on the path where this library produced that input itself. */
+int at_logmel_nonfinite_take(at_ctx* ctx, int32_t* flag, void* stream);
+
 /* counts[t] = number of i with ids[i] == t, t in [0, k) (ids outside are skipped): the token statistics of
  * processors/spec_tokenizer.py:129-147 (a Python Counter over tokens.tolist()) without leaving the device. */
 int at_token_histogram_i64(at_ctx* ctx, const int64_t* ids, int64_t n, int k, int64_t* counts, void* stream);

@@ -620,3 +620,20 @@ def test_kmeans_rejects_non_finite_input(be, oracle, k, niter):
         assert km.iteration_stats == [] and getattr(km, "centroids", None) is None
     km.train(x)                                                    # and the object is still usable
     assert km.centroids.shape == (k, 64) and np.isfinite(km.centroids).all()
+
+
+def test_logmel_propagates_nonfinite_samples_like_the_oracle(be, oracle):
+    """torch.clamp (AmplitudeToDB) leaves a NaN power NaN; so does the oracle; the kernels' `s > 1e-10 ? log : -100`
+    used to turn it into -100 dB (found in round 2 through the fused non-finite verdict)."""
+    import torch
+    from audio_tokens_amd.synth import synth_clips
+    wave = synth_clips(2, L=22050, seed=5, device="cuda")
+    for bad in (float("nan"), float("inf")):
+        w = wave.clone()
+        w[1, 9000] = bad
+        for n_fft in (512, 1024):
+            got = be.logmel(w, n_fft=n_fft, hop=128, n_mels=64).cpu().numpy()
+            want = oracle.logmel(w[1].cpu().numpy(), n_fft=n_fft, hop=128, n_mels=64)
+            assert np.isfinite(got[0]).all()
+            assert np.array_equal(np.isnan(got[1]), np.isnan(want)), (bad, n_fft)
+            assert np.isnan(want).any()

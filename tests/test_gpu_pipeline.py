@@ -291,3 +291,30 @@ def test_generator_with_the_readme_hyperparameters(workdir, oracle):
         assert tuple(sp["spec"].shape) == ref.shape == (64, 1 + 44100 // 512)
         P, Pr = 10.0 ** (sp["spec"].double().numpy() / 10), 10.0 ** (ref.astype(np.float64) / 10)
         assert (np.abs(P - Pr) <= 2e-5 * Pr + 1e-9 * Pr.max(0, keepdims=True) + 1e-14).all()
+
+
+def test_device_pipeline_rejects_nonfinite_input_without_a_scan(be):
+    """faiss' input check (Clustering::train) on the device pipeline: the verdict comes from the unit-row pass of the
+    log-mel kernel (at_logmel_nonfinite_take), not from a second read of the frames; a NaN sample anywhere in a
+    training clip must raise faiss' error, a clean run must not, and the flag must not leak into the next run."""
+    from audio_tokens_amd.pipeline import DevicePipeline
+    from audio_tokens_amd.synth import synth_clips
+    wave = synth_clips(6, L=22050, seed=3, device="cuda")
+    pipe = DevicePipeline(n_mels=64, vocab_size=16, niter=3, clustering_batch_size=6, backend=be)
+    pipe.run(wave[:5], wave[5:])
+    dirty = wave.clone()
+    dirty[2, 7000] = float("nan")
+    with pytest.raises(RuntimeError, match="isfinite"):
+        pipe.run(dirty[:5], dirty[5:])
+    dirty[2, 7000] = float("inf")
+    with pytest.raises(RuntimeError, match="isfinite"):
+        pipe.run(dirty[:5], dirty[5:])
+    pipe.run(wave[:5], wave[5:])                     # the flag was taken: nothing left behind
+    # the flag itself: set by the fused pass and by the stand-alone unit-row kernel (n_mels outside 8..128), cleared by the take
+    for n_mels in (64, 160):
+        assert int(be.logmel_nonfinite_take().item()) == 0
+        be.logmel(dirty[:3], n_mels=n_mels, frame_major=True, l2norm=True)
+        assert int(be.logmel_nonfinite_take().item()) == 1
+        assert int(be.logmel_nonfinite_take().item()) == 0
+        be.logmel(wave[:3], n_mels=n_mels, frame_major=True, l2norm=True)
+        assert int(be.logmel_nonfinite_take().item()) == 0
