@@ -97,10 +97,16 @@ __global__ void __launch_bounds__(WG) visit_keys_kernel(const long* __restrict__
     vals[i] = (uint32_t)i;
 }
 
-__global__ void __launch_bounds__(WG) key_to_hint_kernel(const uint32_t* __restrict__ keys, long n,
-                                                         uint32_t* __restrict__ hint_sorted, int dbits) {
+// the sorted keys give the guesses in visiting order; the sorted values (row indices) leave the sort's buffer in the same pass
+__global__ void __launch_bounds__(WG) key_to_hint_kernel(const uint32_t* __restrict__ keys,
+                                                         const uint32_t* __restrict__ vals, long n,
+                                                         uint32_t* __restrict__ hint_sorted,
+                                                         uint32_t* __restrict__ order_out, int dbits) {
     const long i = (long)blockIdx.x * WG + threadIdx.x;
-    if (i < n) hint_sorted[i] = keys[i] >> dbits;
+    if (i < n) {
+        hint_sorted[i] = keys[i] >> dbits;
+        order_out[i] = vals[i];
+    }
 }
 
 __global__ void __launch_bounds__(WG) max_sqnorm_kernel(const float* __restrict__ C, int k, int d,
@@ -432,9 +438,8 @@ int at_visit_order_f32(at_ctx* ctx, const int64_t* ids, const float* dis, int64_
     void* tmp = at_ws(ctx, WS_VISIT_TMP, tmp_bytes, stream);
     if (!tmp) return AT_E_NOMEM;
     AT_HIP(rocprim::radix_sort_pairs<at_radix_config>(tmp, tmp_bytes, kb, vb, (size_t)n, 0, bits, stream));
-    AT_HIP(hipMemcpyAsync(order_out, vb.current(), sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream));
     hipLaunchKernelGGL(key_to_hint_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, stream, kb.current(),
-                       (long)n, hint_sorted_out, dbits);
+                       vb.current(), (long)n, hint_sorted_out, order_out, dbits);
     AT_LAUNCH_CHECK();
     return AT_OK;
 }
