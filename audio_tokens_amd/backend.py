@@ -605,22 +605,35 @@ class HipBackend(HostHelpers):
             _lib.check(self.lib.at_split_clusters_f32(self.ctx.handle, d, k, n, _ptr(hassign), _ptr(cent), _ptr(nsplit_out),
                                                       self._stream()))
 
+    def _objective_parts(self, parts, k, d, objs):
+        if objs is not None:
+            assert objs.dtype == torch.float64 and objs.is_contiguous()
+            return _ptr(objs), 1, objs.numel()
+        if parts.dim() == 1:
+            parts = parts.unsqueeze(0)
+        off, total = self.part_layout(k, d)
+        assert parts.is_contiguous() and parts.shape[1] == total
+        return _vp(parts.data_ptr() + 4 * off), total // 2, parts.shape[0]
+
     def lloyd_stats(self, hassign, parts, k: int, d: int, stats_row, objs=None) -> None:
         """stats_row (float64 [2]) <- (objective summed in rank order, imbalance).  The per-rank objectives are the
         doubles riding at the end of the packed partials, or -- objs given -- a float64 tensor [n_ranks]."""
         assert stats_row.dtype == torch.float64
-        if objs is not None:
-            assert objs.dtype == torch.float64 and objs.is_contiguous()
-            ptr, stride, n_parts = _ptr(objs), 1, objs.numel()
-        else:
-            if parts.dim() == 1:
-                parts = parts.unsqueeze(0)
-            off, total = self.part_layout(k, d)
-            assert parts.is_contiguous() and parts.shape[1] == total
-            ptr, stride, n_parts = _vp(parts.data_ptr() + 4 * off), total // 2, parts.shape[0]
+        ptr, stride, n_parts = self._objective_parts(parts, k, d, objs)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.at_lloyd_stats_f64(self.ctx.handle, _ptr(hassign), k, ptr, stride, n_parts, _ptr(stats_row),
                                                    self._stream()))
+
+    def lloyd_stats_split(self, hassign, cent, n: int, nsplit_out, parts, stats_row, objs=None) -> None:
+        """lloyd_stats followed by split_clusters_device, one launch (at_lloyd_stats_split_f32)."""
+        k, d = cent.shape
+        assert stats_row.dtype == torch.float64 and nsplit_out.dtype == torch.int32
+        assert hassign.dtype == torch.float32 and cent.dtype == torch.float32
+        assert hassign.is_contiguous() and cent.is_contiguous() and hassign.numel() == k
+        ptr, stride, n_parts = self._objective_parts(parts, k, d, objs)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_lloyd_stats_split_f32(self.ctx.handle, d, k, n, _ptr(hassign), _ptr(cent), _ptr(nsplit_out),
+                                                         ptr, stride, n_parts, _ptr(stats_row), self._stream()))
 
     def sum_parts(self, parts) -> torch.Tensor:
         """parts [n_parts, m] float32 -> [m]: added in ascending part order (at_sum_parts_f32)."""

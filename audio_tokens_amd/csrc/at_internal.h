@@ -51,6 +51,7 @@ enum at_ws_slot {
     WS_LONG_LATE,      // centroid_accum: long clusters left to the pass behind the sort
     WS_BUCKETS,        // centroid_accum bucket path: counts, cursors, the list of long clusters
     WS_LOGMEL_ANY,     // log-mel, general n_fft: window, twiddles, banded filterbank
+    WS_SUM_TICKET,     // at_sum_f32: arrival counter of its workgroups (the last one adds the partials up), zero between calls
     WS_ROW_FLAG,       // one int: a unit-row pass of at_logmel_f32 met a row whose squared norm is not finite
     WS_FILTER_BLKSTATS, // fp16-split filter: one statistics record per workgroup of a sweep (switch filter_stats)
     WS_NSLOTS

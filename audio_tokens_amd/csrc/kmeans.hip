@@ -621,26 +621,37 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-__global__ void __launch_bounds__(WG) sum_partial_kernel(const float* __restrict__ v, long n,
-                                                         double* __restrict__ partial) {
+// One launch: every workgroup leaves its partial sum, the last one to arrive (a counter that it also puts back to
+// zero) adds the partials up in index order with the same tree the separate second kernel of round 1 used -- the
+// same bits, one launch less in every Lloyd iteration.
+__global__ void __launch_bounds__(WG) sum_kernel(const float* __restrict__ v, long n, double* __restrict__ partial,
+                                                 unsigned* __restrict__ ticket, double* __restrict__ out) {
     __shared__ double sh[WG / 64];
+    __shared__ bool last;
     double acc = 0.0;
     for (long i = (long)blockIdx.x * WG + threadIdx.x; i < n; i += (long)gridDim.x * WG) acc += (double)v[i];
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-}
-
-__global__ void __launch_bounds__(WG) sum_final_kernel(const double* __restrict__ partial, int m,
-                                                       double* __restrict__ out) {
-    __shared__ double sh[WG / 64];
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < m; i += WG) acc += partial[i];
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&partial[blockIdx.x], (sh[0] + sh[1]) + (sh[2] + sh[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;          // (uniform over the workgroup)
+    __threadfence();
+    const int m = (int)gridDim.x;
+    acc = 0.0;
+    for (int i = threadIdx.x; i < m; i += WG) acc += __hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     acc = wave_sum(acc);
+    __syncthreads();
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) *out = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    if (threadIdx.x == 0) {
+        *out = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        *ticket = 0u;
+    }
 }
 
 __global__ void __launch_bounds__(WG) nonfinite_kernel(const float* __restrict__ v, long n,
@@ -1005,9 +1016,11 @@ int at_sum_f32(at_ctx* ctx, const float* v, int64_t n, double* out, void* stream
     int blocks = (int)((n + WG - 1) / WG);
     if (blocks > RED_BLOCKS) blocks = RED_BLOCKS;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(sum_partial_kernel, dim3(blocks), dim3(WG), 0, stream, v, (long)n, partial);
-    AT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(WG), 0, stream, partial, blocks, out);
+    const bool fresh = ctx->ws[WS_SUM_TICKET] == nullptr;
+    unsigned* ticket = static_cast<unsigned*>(at_ws(ctx, WS_SUM_TICKET, 16, stream));
+    if (!ticket) return AT_E_NOMEM;
+    if (fresh) AT_HIP(hipMemsetAsync(ticket, 0, 16, stream));
+    hipLaunchKernelGGL(sum_kernel, dim3(blocks), dim3(WG), 0, stream, v, (long)n, partial, ticket, out);
     AT_LAUNCH_CHECK();
     return AT_OK;
 }

@@ -31,13 +31,50 @@ constexpr int SPLIT_ROUND = SPLIT_BLOCKS * WG;   // candidates tested per step w
 // RandomGenerator::rand_float: mt() / float(mt.max()) -- float(2^32 - 1) is 2^32
 __device__ __forceinline__ float rand_float_of(uint32_t raw) { return __uint2float_rn(raw) * 2.3283064365386963e-10f; }
 
+// stats[0] = sum over the parts (ascending) of the double at obj_parts[p * stride];
+// stats[1] = faiss imbalance_factor = k * sum(h^2) / (sum h)^2 (the sums are of integers < 2^53: exact in any order)
+// (one workgroup of WG threads; every thread calls it)
+__device__ void lloyd_stats_block(const float* __restrict__ hassign, int k, const double* obj_parts, long obj_stride,
+                                  int n_parts, double* __restrict__ stats) {
+    __shared__ double s1[WG / 64], s2[WG / 64];
+    const int t = threadIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int c = t; c < k; c += WG) {
+        const double h = (double)hassign[c];
+        a += h;
+        b += h * h;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off);
+        b += __shfl_down(b, off);
+    }
+    if ((t & 63) == 0) { s1[t >> 6] = a; s2[t >> 6] = b; }
+    __syncthreads();
+    if (t == 0) {
+        double tot = 0.0, sq = 0.0;
+        for (int w = 0; w < WG / 64; w++) { tot += s1[w]; sq += s2[w]; }
+        double obj = 0.0;
+        for (int p = 0; p < n_parts; p++) obj += obj_parts[(size_t)p * obj_stride];
+        stats[0] = obj;
+        stats[1] = sq * k / (tot * tot);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(WG) void lloyd_stats_kernel(const float* __restrict__ hassign, int k, const double* obj_parts,
+                                                        long obj_stride, int n_parts, double* __restrict__ stats) {
+    lloyd_stats_block(hassign, k, obj_parts, obj_stride, n_parts, stats);
+}
+
 // raw / raw_n: the first raw_n outputs of mt19937(1234), resident (at_mt_cached_draws); state_end: the generator's
 // 624 state words after them, from which the kernel goes on by itself if a repair ever needs more.
 // p_lds != 0: the acceptance probabilities of all k clusters live in LDS (k floats of dynamic shared memory).
 __global__ __launch_bounds__(WG) void split_clusters_kernel(int d, int k, long n, float* hassign, float* cent,
                                                            int* __restrict__ empties, int* __restrict__ nsplit_out,
                                                            const uint32_t* __restrict__ raw, long raw_n,
-                                                           const uint32_t* __restrict__ state_end, int p_lds) {
+                                                           const uint32_t* __restrict__ state_end, int p_lds,
+                                                           const double* obj_parts, long obj_stride, int n_parts,
+                                                           double* __restrict__ stats) {
     extern __shared__ float pl[];
     __shared__ at_mt::State mt;
     __shared__ float draws[at_mt::N];
@@ -45,6 +82,8 @@ __global__ __launch_bounds__(WG) void split_clusters_kernel(int d, int k, long n
     __shared__ int n_empty;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
+    // (optional) the iteration's statistics first: they describe the counts as the assignment left them
+    if (stats) lloyd_stats_block(hassign, k, obj_parts, obj_stride, n_parts, stats);
     // the usual iteration has no empty cluster: one pass and one barrier settle that
     {
         bool any = false;
@@ -194,41 +233,21 @@ __global__ __launch_bounds__(WG) void split_clusters_kernel(int d, int k, long n
     if (t == 0) *nsplit_out = done == ne ? ne : -1;
 }
 
-// stats[0] = sum over the parts (ascending) of the double at obj_parts[p * stride];
-// stats[1] = faiss imbalance_factor = k * sum(h^2) / (sum h)^2 (the sums are of integers < 2^53: exact in any order)
-__global__ __launch_bounds__(WG) void lloyd_stats_kernel(const float* __restrict__ hassign, int k, const double* obj_parts,
-                                                        long obj_stride, int n_parts, double* __restrict__ stats) {
-    __shared__ double s1[WG / 64], s2[WG / 64];
-    const int t = threadIdx.x;
-    double a = 0.0, b = 0.0;
-    for (int c = t; c < k; c += WG) {
-        const double h = (double)hassign[c];
-        a += h;
-        b += h * h;
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        a += __shfl_down(a, off);
-        b += __shfl_down(b, off);
-    }
-    if ((t & 63) == 0) { s1[t >> 6] = a; s2[t >> 6] = b; }
-    __syncthreads();
-    if (t == 0) {
-        double tot = 0.0, sq = 0.0;
-        for (int w = 0; w < WG / 64; w++) { tot += s1[w]; sq += s2[w]; }
-        double obj = 0.0;
-        for (int p = 0; p < n_parts; p++) obj += obj_parts[(size_t)p * obj_stride];
-        stats[0] = obj;
-        stats[1] = sq * k / (tot * tot);
-    }
-}
-
 }  // namespace
 
 extern "C" {
 
 int at_split_clusters_f32(at_ctx* ctx, int d, int k, int64_t n, float* hassign, float* centroids, int32_t* nsplit_out,
                           void* stream_) {
+    return at_lloyd_stats_split_f32(ctx, d, k, n, hassign, centroids, nsplit_out, nullptr, 0, 0, nullptr, stream_);
+}
+
+int at_lloyd_stats_split_f32(at_ctx* ctx, int d, int k, int64_t n, float* hassign, float* centroids, int32_t* nsplit_out,
+                             const double* obj_parts, int64_t obj_part_stride, int n_parts, double* stats, void* stream_) {
     AT_REQUIRE(ctx && hassign && centroids && nsplit_out && d > 0 && k > 0 && n >= k, "at_split_clusters_f32: bad arguments");
+    AT_REQUIRE(!stats || (obj_parts && n_parts >= 1 && (reinterpret_cast<uintptr_t>(obj_parts) & 7u) == 0 &&
+                          (reinterpret_cast<uintptr_t>(stats) & 7u) == 0),
+               "at_lloyd_stats_split_f32: obj_parts / stats must be given together, 8-byte aligned");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     AT_HIP(hipSetDevice(ctx->device));
     int* empties = static_cast<int*>(at_ws(ctx, WS_SPLIT_LIST, (size_t)k * sizeof(int), stream));
@@ -248,7 +267,7 @@ int at_split_clusters_f32(at_ctx* ctx, int d, int k, int64_t n, float* hassign, 
         }
     }
     hipLaunchKernelGGL(split_clusters_kernel, dim3(1), dim3(WG), lds, stream, d, k, (long)n, hassign, centroids, empties,
-                       nsplit_out, raw, (long)raw_n, state_end, p_lds);
+                       nsplit_out, raw, (long)raw_n, state_end, p_lds, obj_parts, (long)obj_part_stride, n_parts, stats);
     AT_LAUNCH_CHECK();
     return AT_OK;
 }

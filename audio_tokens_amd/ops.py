@@ -428,12 +428,15 @@ class Kmeans:
                 red[0, obj_off:] = 0.0
                 objs = dist.all_gather_f64(part[obj_off:obj_off + 2].view(torch.float64))
                 cent, hassign = be.centroid_finalize(red, k, d)
-                be.lloyd_stats(hassign, red, k, d, stats_dev[it], objs=objs.contiguous())
+                parts, objs = red, objs.contiguous()
             else:
-                parts = dist.all_gather_parts(part)
+                parts, objs = dist.all_gather_parts(part), None
                 cent, hassign = be.centroid_finalize(parts, k, d)
-                be.lloyd_stats(hassign, parts, k, d, stats_dev[it])
-            be.split_clusters_device(hassign, cent, ns, nsplit_dev[it:it + 1])
+            if hasattr(be, "lloyd_stats_split"):    # statistics + repair of empty clusters: two single-workgroup passes, one launch
+                be.lloyd_stats_split(hassign, cent, ns, nsplit_dev[it:it + 1], parts, stats_dev[it], objs=objs)
+            else:
+                be.lloyd_stats(hassign, parts, k, d, stats_dev[it], objs=objs)
+                be.split_clusters_device(hassign, cent, ns, nsplit_dev[it:it + 1])
             tp = lap("exchange+finalize+split", tp)
             if prune and timed_events:
                 paced.append(be.record_event_timed())

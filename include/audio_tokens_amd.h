@@ -258,6 +258,12 @@ int at_split_clusters_f32(at_ctx* ctx, int d, int k, int64_t n, float* hassign, 
 int at_lloyd_stats_f64(at_ctx* ctx, const float* hassign, int k, const double* obj_parts,
                        int64_t obj_part_stride, int n_parts, double* stats, void* stream);
 
+/* at_lloyd_stats_f64 followed by at_split_clusters_f32 in ONE launch (both are single-workgroup kernels over the k
+ * counts; a Lloyd iteration of a sharded run is short enough for the launch between them to matter).  stats may be
+ * null: then exactly at_split_clusters_f32. */
+int at_lloyd_stats_split_f32(at_ctx* ctx, int d, int k, int64_t n, float* hassign, float* centroids, int32_t* nsplit_out,
+                             const double* obj_parts, int64_t obj_part_stride, int n_parts, double* stats, void* stream);
+
 /* *out (DEVICE double) = sum of v[0..n) accumulated in double with a fixed reduction tree. */
 int at_sum_f32(at_ctx* ctx, const float* v, int64_t n, double* out, void* stream);
 
