@@ -97,6 +97,29 @@ def test_lloyd_stats(be):
     assert st[1] == (hd * hd).sum() * k / (hd.sum() ** 2)
 
 
+@pytest.mark.parametrize("k,d,n,n_empty", [(64, 64, 4096, 3), (8192, 64, 2097152, 0), (8192, 64, 2097152, 40), (500, 64, 128000, 0)])
+def test_lloyd_stats_split_in_one_launch(be, k, d, n, n_empty):
+    """at_lloyd_stats_split_f32 == at_lloyd_stats_f64 followed by at_split_clusters_f32, bit for bit: the statistics
+    describe the counts as the assignment left them, the repair then changes counts and centroids."""
+    rng = np.random.default_rng(k + n_empty + 1)
+    h, c = _split_case(rng, k, d, n, n_empty, None)
+    off, total = be.part_layout(k, d)
+    parts = torch.zeros((2, total), dtype=torch.float32, device=be.device)
+    parts[0, off:off + 2].view(torch.float64)[0] = 3.25
+    parts[1, off:off + 2].view(torch.float64)[0] = 1e-7
+    h1, c1, h2, c2 = be.from_host(h), be.from_host(c), be.from_host(h), be.from_host(c)
+    st1 = torch.zeros((2,), dtype=torch.float64, device=be.device)
+    st2 = torch.zeros((2,), dtype=torch.float64, device=be.device)
+    ns1 = torch.full((1,), -7, dtype=torch.int32, device=be.device)
+    ns2 = torch.full((1,), -7, dtype=torch.int32, device=be.device)
+    be.lloyd_stats(h1, parts, k, d, st1)
+    be.split_clusters_device(h1, c1, n, ns1)
+    be.lloyd_stats_split(h2, c2, n, ns2, parts, st2)
+    assert int(ns1.item()) == int(ns2.item()) == n_empty
+    assert torch.equal(st1.view(torch.int64), st2.view(torch.int64))
+    assert torch.equal(h1.view(torch.int32), h2.view(torch.int32)) and torch.equal(c1.view(torch.int32), c2.view(torch.int32))
+
+
 @pytest.mark.parametrize("sync", [True, False])
 def test_kmeans_train_without_host_round_trips_matches_oracle(be, oracle, sync):
     """The restructured loop (device permutation, device split_clusters, statistics read at the end) against

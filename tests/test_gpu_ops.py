@@ -354,6 +354,15 @@ def test_sum_and_nonfinite(be):
     assert be.any_nonfinite(v)
     v[12345] = np.nan
     assert be.any_nonfinite(v)
+    # one launch, the last workgroup adds the partials: the same bits every time, at every size, and the arrival
+    # counter is back at zero after each call
+    for n in (0, 1, 255, 256, 257, 70_000, 262_144 + 5, 3_000_001):
+        w = rng.standard_normal(n).astype(np.float32)
+        wt = be.from_host(w)
+        first = be.sum_f64(wt).item()
+        for _ in range(3):
+            assert be.sum_f64(wt).item() == first
+        assert abs(first - w.astype(np.float64).sum()) <= 1e-9 * max(1.0, np.abs(w).astype(np.float64).sum())
 
 
 def _logmel_tolerance(got, ref):
