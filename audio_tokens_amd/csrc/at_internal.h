@@ -78,7 +78,7 @@ struct at_debug {
     int prune_kernel;     // AT_PRUNE_KERNEL     0 = LDS-DMA form of the d = 64 fp32 pruned sweep
     int prune_nb;         // AT_PRUNE_NB         row tiles per wave of the fp32 pruned sweep (1, 2, 4; 0 = default)
     int filter_screen;    // AT_FILTER_SCREEN    0 = always evaluate all three fp16 products
-    int filter_nb;        // AT_FILTER_NB        row tiles per wave of the filter sweep (2, 4; 0 = by size)
+    int filter_nb;        // AT_FILTER_NB        row tiles per wave of the filter sweep (1, 2, 4; 0 = by size)
     int filter_wps2;      // AT_FILTER_WPS2      1 = two waves per SIMD in the Lloyd-sized filter sweeps
     int dmin_kernel;      // AT_DMIN_KERNEL      0 = fp32 vector-ALU kernel for the centroid-to-group bounds
     int resample_simple;  // AT_RESAMPLE_SIMPLE  1 = one-thread-per-sample resampler

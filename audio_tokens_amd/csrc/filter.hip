@@ -138,7 +138,7 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
                         float tau_b, float rho_a, float rho_b, int screen, int collect, long* __restrict__ ids,
                         uint32_t* __restrict__ amb_list, uint32_t* __restrict__ amb_aux,
                         float* __restrict__ approx_out, FusedPrepass fp, uint4* __restrict__ blk_stats, unsigned amb_cap) {
-    static_assert(NB == 2 || NB == 4, "tiles are processed in pairs");
+    static_assert(NB == 1 || NB == 2 || NB == 4, "tiles are processed in pairs (NB = 1: a pair whose second tile does not exist)");
     // blk_stats (may be null = statistics off): one record per workgroup {groups needed, groups of the dense sweep,
     // tiles multiplied hi*hi, tiles refined}, summed by filter_stats_reduce_kernel.  Round 1 added these with
     // atomics on 16 + 256 hot words from all 32 768 workgroups of a Lloyd sweep: 40 us of a 600 us kernel.
@@ -148,7 +148,7 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
     __shared__ unsigned short glist[512];
     __shared__ uint32_t maskl[NB][16];   // (fused coarse mode) the tiles' group masks
     // per-row values that only the epilogue needs sit out the walk in LDS (the walk is short of registers)
-    constexpr bool STASH = NB == 2;      // (four tiles already fill the CU's LDS with the lo parts of the rows)
+    constexpr bool STASH = NB <= 2;      // (four tiles already fill the CU's LDS with the lo parts of the rows)
     __shared__ float stash_tau[STASH ? NB : 1][64], stash_gbd[STASH ? NB : 1][64];
     __shared__ unsigned stash_row[STASH ? NB : 1][64], stash_hint[STASH ? NB : 1][64];
     const unsigned char* img_cur = img;  // the image the walk reads: the centroids', or first the group means'
@@ -445,11 +445,11 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
         half8 al[NS];
         bool have_al = false;
 #pragma unroll
-        for (int pr = 0; pr < NB / 2; pr++) {  // tiles in pairs: two independent accumulator chains, interleaved
-            constexpr int dummy = 0;
-            (void)dummy;
-            const int t0 = 2 * pr, t1 = 2 * pr + 1;
-            const bool need0 = (e >> (9 + t0)) & 1, need1 = (e >> (9 + t1)) & 1;  // wave-uniform
+        for (int pr = 0; pr < (NB + 1) / 2; pr++) {  // tiles in pairs: two independent accumulator chains, interleaved
+            const int t0 = 2 * pr;
+            const bool second = 2 * pr + 1 < NB;             // (NB = 1: the pair's second tile does not exist)
+            const int t1 = second ? 2 * pr + 1 : t0;
+            const bool need0 = (e >> (9 + t0)) & 1, need1 = second && ((e >> (9 + 2 * pr + 1)) & 1);  // wave-uniform
             if (!(need0 || need1)) continue;
             n_hh += (unsigned)need0 + (unsigned)need1;
             f32x16 a0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1188,10 +1188,13 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
     // Rows per wave = 32 * NB.  Lloyd-sized exact sweeps (rows sorted by guess, <= 8 M of them) run two
     // tiles per wave at three waves per SIMD (168 registers, no second fragment set: occupancy hides the
     // loads; 3 % faster than four tiles at two waves); the long tokenise sweeps and the guess generators
-    // keep four tiles per wave.  AT_FILTER_NB=2|4 forces the choice (A/B aid).
+    // keep four tiles per wave.  AT_FILTER_NB=1|2|4 forces the choice (A/B aid).
     const int nbv = ctx->dbg.filter_nb;
-    const bool wps3 = fused && d == 64 && (nbv ? nbv == 2 : n <= (int64_t)8 << 20) && !ctx->dbg.filter_wps2;
-    const int NB = (wps3 || nbv == 2) ? 2 : 4;
+    // Short sweeps (a shard of an N-GPU run: 262 144 rows are 4096 two-tile waves for 3072 slots, i.e. two rounds where
+    // 1.33 would do) run ONE tile per wave at four waves per SIMD: 8192 half-size waves on 4096 slots.
+    const bool one_tile = fused && d == 64 && !ctx->dbg.filter_wps2 && (nbv ? nbv == 1 : n <= (int64_t)1 << 19);
+    const bool wps3 = !one_tile && fused && d == 64 && (nbv ? nbv == 2 : n <= (int64_t)8 << 20) && !ctx->dbg.filter_wps2;
+    const int NB = one_tile ? 1 : (wps3 || nbv == 2) ? 2 : 4;
     const dim3 grid((unsigned)((n + 32 * NB - 1) / (32 * NB)));
     AT_REQUIRE(d == 64 || d == 128, "at_filter_sweep: d must be 64 or 128");
     // statistics (switch filter_stats; off by default): one record per workgroup, summed behind the sweep
@@ -1223,6 +1226,10 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
         if (fused) AT_FILTER_LAUNCH(64, 4, false, true, grid);
         else if (collect) AT_FILTER_LAUNCH(64, 4, false, false, grid);
         else AT_FILTER_LAUNCH(64, 4, true, false, grid);
+    } else if (one_tile) {
+        hipLaunchKernelGGL((assign_f16filter_kernel<64, 1, false, true, 4>), grid, dim3(64), 0, stream, x, (long)n, img, ng,
+                           order, bd, mask, ngw, misc, ta, tb, ra, rb, screen, collect, reinterpret_cast<long*>(ids),
+                           amb_list, amb_aux, approx_out, fp, blk_stats, amb_cap);
     } else {
         if (wps3) {
             hipLaunchKernelGGL((assign_f16filter_kernel<64, 2, false, true, 3>), grid, dim3(64), 0, stream, x, (long)n, img, ng,

@@ -88,14 +88,16 @@ def test_kmeans_pruned_path_matches_oracle(be, oracle, switches):
         warnings.simplefilter("ignore")
         r1 = oracle.kmeans_train(x[:40000], 2048, niter=8)
         r2 = oracle.kmeans_train(x[40000:], 2048, niter=8, init_centroids=r1.centroids)
-        for prune in (True, False):
+        # tiles per wave of the Lloyd sweep: the default at this size (one), and two / four forced
+        for prune, nb in ((True, 0), (True, 2), (True, 4), (False, 0)):
+            switches(filter_nb=nb)
             km = Kmeans(64, 2048, niter=8)
             km.prune = prune
             km.train(x[:40000])
-            assert np.array_equal(bits(km.centroids), bits(r1.centroids)), f"prune={prune} cold"
+            assert np.array_equal(bits(km.centroids), bits(r1.centroids)), f"prune={prune} nb={nb} cold"
             assert [s["nsplit"] for s in km.iteration_stats] == list(r1.nsplit)
             km.train(x[40000:], init_centroids=km.centroids)
-            assert np.array_equal(bits(km.centroids), bits(r2.centroids)), f"prune={prune} warm"
+            assert np.array_equal(bits(km.centroids), bits(r2.centroids)), f"prune={prune} nb={nb} warm"
     a, t = be.prune_stats()
     assert 0 < a < t                                         # something was really skipped
 

@@ -270,7 +270,8 @@ def test_l2norm_rows_bit_exact_vs_numpy(be, n, d):
     ref = x / (np.linalg.norm(x, axis=1, keepdims=True) + 1e-10)
     got = be.l2norm_rows(x).cpu().numpy()
     assert ref.dtype == np.float32
-    assert np.array_equal(bits(got), bits(ref))
+    diff = np.argwhere(bits(got) != bits(ref))
+    assert diff.size == 0, f"{len(diff)} of {got.size} values differ, first at {diff[0]}: got {got[tuple(diff[0])]!r} want {ref[tuple(diff[0])]!r}"
 
 
 def test_gather_rows(be):
