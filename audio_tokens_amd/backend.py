@@ -147,7 +147,9 @@ class HipBackend(HostHelpers):
         if t.dtype != torch.float32:
             t = t.float()
         if t.device != self.device:
-            t = t.to(self.device, non_blocking=True)
+            # (asynchronous only from pinned memory: a pageable source -- often a temporary made two lines up -- must have
+            # been read by the time this returns, and torch does not wait for a non_blocking copy of one)
+            t = t.to(self.device, non_blocking=t.is_pinned() if t.device.type == "cpu" else True)
         if not t.is_contiguous():
             t = t.contiguous()
         return t

@@ -1013,8 +1013,11 @@ int at_sum_f32(at_ctx* ctx, const float* v, int64_t n, double* out, void* stream
     AT_HIP(hipSetDevice(ctx->device));
     double* partial = static_cast<double*>(at_ws(ctx, WS_REDUCE, RED_BLOCKS * sizeof(double), stream));
     if (!partial) return AT_E_NOMEM;
-    int blocks = (int)((n + WG - 1) / WG);
-    if (blocks > RED_BLOCKS) blocks = RED_BLOCKS;
+    // one workgroup per CU at most: every workgroup ends with an atomic on the one arrival counter, and a thousand of
+    // those in a row cost more (15 us) than the sum itself
+    int blocks = (int)((n + 4 * WG - 1) / (4 * WG));
+    const int cap = n <= ((int64_t)1 << 22) ? 256 : RED_BLOCKS;   // (long vectors want the bandwidth of more workgroups)
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     const bool fresh = ctx->ws[WS_SUM_TICKET] == nullptr;
     unsigned* ticket = static_cast<unsigned*>(at_ws(ctx, WS_SUM_TICKET, 16, stream));

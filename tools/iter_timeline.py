@@ -8,7 +8,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-sw = [i for i, r in enumerate(rows) if "assign_f16filter_kernel<64, 2, false, true" in r["Kernel_Name"]]
+sw = [i for i, r in enumerate(rows) if "assign_f16filter_kernel<64, " in r["Kernel_Name"] and "false, true" in r["Kernel_Name"]]
 a, b = sw[which], sw[which + 1]
 t0 = int(rows[a]["Start_Timestamp"])
 lo = a
