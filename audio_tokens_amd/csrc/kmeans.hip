@@ -332,9 +332,10 @@ __global__ void __launch_bounds__(1024) early_scan_kernel(const uint32_t* __rest
         part[m][t] = s;
     }
     __syncthreads();
-    if (t < EARLY_MAX) {   // (eight serial scans of 1024 side by side)
+    if (t < EARLY_MAX) {   // (serial scans side by side, over the threads that hold blocks: 64 of them at 262 144 rows)
+        const int used = min(1024, (nblk + per - 1) / per);
         uint32_t run = 0;
-        for (int i = 0; i < 1024; i++) { const uint32_t v = part[t][i]; part[t][i] = run; run += v; }
+        for (int i = 0; i < used; i++) { const uint32_t v = part[t][i]; part[t][i] = run; run += v; }
         total[t] = run;
     }
     __syncthreads();
