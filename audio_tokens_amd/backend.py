@@ -124,6 +124,7 @@ class HipBackend(HostHelpers):
         self.device = device
         self.ctx = _lib.context(device.index)
         self.assign_trace = None  # set to a list to collect (kind, n, d, k, start_event, end_event)
+        self.assign_trace_only = None   # a set of kinds: only those are traced (every traced launch is two events on the stream)
         # host-side A/B switches, read from the environment once (the native ones: at_debug.h, self.debug_set)
         self.switches = {"filter": os.environ.get("AT_FILTER", "1") != "0",
                          "c2f_fused": os.environ.get("AT_C2F_FUSED", "1") != "0"}
@@ -153,6 +154,11 @@ class HipBackend(HostHelpers):
         if not t.is_contiguous():
             t = t.contiguous()
         return t
+
+    def _trace_list(self, kind):
+        if self.assign_trace is None or (self.assign_trace_only is not None and kind not in self.assign_trace_only):
+            return None
+        return self.assign_trace
 
     def empty(self, shape, dtype=torch.float32) -> torch.Tensor:
         return torch.empty(shape, dtype=dtype, device=self.device)
@@ -227,7 +233,7 @@ class HipBackend(HostHelpers):
             out = self.empty(shape)
         else:
             assert out.is_contiguous() and out.dtype == torch.float32 and out.numel() == n_clips * T * n_mels
-        rec = self.assign_trace
+        rec = self._trace_list("logmel")
         if rec is not None:  # bench.py: HIP events on the launch stream around the launch
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.device))
@@ -305,7 +311,7 @@ class HipBackend(HostHelpers):
         k = c.shape[0]
         ids = self.empty((n,), torch.int64)
         dist = self.empty((n,), torch.float32) if want_dist else None
-        rec = self.assign_trace
+        rec = self._trace_list("plain")
         if rec is not None:  # bench.py: HIP events on the launch stream around every assign launch
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.device))
@@ -333,7 +339,7 @@ class HipBackend(HostHelpers):
                 assert t.dtype == torch.int32 and t.is_contiguous() and t.numel() == n
         ids = self.empty((n,), torch.int64)
         dist = self.empty((n,), torch.float32) if want_dist else None
-        rec = self.assign_trace
+        rec = self._trace_list("hinted")
         if rec is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.device))
@@ -481,7 +487,7 @@ class HipBackend(HostHelpers):
         ng = cperm.numel() // 32
         ids = self.empty((n,), torch.int64)
         dist = self.empty((n,), torch.float32) if want_dist else None
-        rec = self.assign_trace
+        rec = self._trace_list("pruned" if mode == 0 else "coarse")
         # exact filtered calls do their pre-pass (guess distances + group masks) inside the sweep kernel
         fused = use_filter and mode == 0 and self.debug_get("filter_fused") != 0
         with torch.cuda.device(self.device):
