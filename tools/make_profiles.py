@@ -28,7 +28,7 @@ for r in tr:
         filt[r["Kernel_Name"][r["Kernel_Name"].index("assign_f16filter_kernel"):].split("(")[0]].append(dur(r))
 with open(os.path.join(P, f"{tag}_bench_kernel_stats_top.txt"), "w") as f:
     f.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline   (MI355X, 1 GPU)\n")
-    f.write("6 pipeline runs in the process (1 warm-up + 3 timed + 1 per-stage split + 1 dense floor); the torch kernels that generate\n"
+    f.write("7 pipeline runs in the process (1 warm-up + 1 traced + 3 timed + 1 per-stage split + 1 dense floor); the torch kernels that generate\n"
             "the synthetic waveforms are left out of the table below (they are in the .csv).\n")
     f.write(f"bench line of this run: {d['value']:.4g} frames/s, {d['ms_per_step']:.1f} ms/step, verified={d['verified']}\n\n")
     f.write("exact filter sweeps (the roofline kernel of bench.py), by instantiation:\n")
