@@ -19,6 +19,11 @@ centroid normalisation -> nearest-centroid tokens for every frame.  Nothing is c
 the next (the subsample permutation is computed inside every step, on the device).  Inputs are in HBM before
 the timed region starts.  Rank 0 prints ONE JSON line.
 
+Kernel times for the roofline come from HIP events inside the timed steps: the pair the library records around the
+fp16 filter sweep on every exact call, or -- when another kernel class dominates -- a pair around each launch of that
+class.  Which class dominates is decided by one extra UNTIMED step behind the W warm-up steps in which every launch
+is bracketed (`traced_step_ms`, `roofline.kernel_classes`); with W = 0 the timed steps themselves are traced in full.
+
 Outside the timed region the same step is run once more with every acceleration off (dense fp32 sweeps):
 `dense_floor` is its rate -- what the path does on data that defeats the pruning -- and `verified` says its
 tokens and centroids equal the timed configuration's bit for bit.
