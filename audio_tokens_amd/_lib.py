@@ -66,6 +66,8 @@ SIGNATURES = {
     "at_centroid_finalize_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "at_split_clusters_f32": (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
     "at_lloyd_stats_f64": (_i32, [_vp, _vp, _i32, _vp, _i64, _i32, _vp, _vp]),
+    "at_comm_allgather_f32": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "at_comm_allreduce_ordered_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "at_lloyd_stats_split_f32": (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "at_sum_parts_f32": (_i32, [_vp, _vp, _i64, _i32, _i64, _vp, _vp]),
     "at_sum_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),

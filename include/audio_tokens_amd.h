@@ -51,6 +51,7 @@ extern "C" {
 #define AT_E_NOMEM (-3)    /* workspace allocation failed */
 #define AT_E_TOO_FEW (-4)  /* faiss: "Number of training points should be at least ..." */
 #define AT_E_NONFINITE (-5)/* faiss: "input contains NaN's or Inf's" */
+#define AT_E_COMM (-6)     /* RCCL is not available in the process, or a collective failed */
 
 /* at_logmel_f32 output layouts */
 #define AT_LAYOUT_MEL_MAJOR 0   /* out[clip][n_mels][T]  -- the reference's .npy file layout */
@@ -244,6 +245,16 @@ int at_centroid_finalize_f32(at_ctx* ctx, const float* sums_parts, int64_t sums_
  * all-gather instead of an all-gather of whole partials (same bits as at_centroid_finalize_f32 over all parts). */
 int at_sum_parts_f32(at_ctx* ctx, const float* parts, int64_t part_stride, int n_parts, int64_t m, float* out,
                      void* stream);
+
+/* The exchange itself, for hosts that do not go through torch.distributed (the Python layer does: ops._Dist):
+ * thin wrappers over RCCL on the CALLER's communicator (`nccl_comm` is an ncclComm_t; RCCL is looked up at run time,
+ * the library has no link-time dependency on it).  at_comm_allgather_f32: parts [n_ranks][count] <- every rank's
+ * part [count].  at_comm_allreduce_ordered_f32: out [count] <- the parts added in ascending rank order (all-gather into
+ * parts_scratch [n_ranks * count], then at_sum_parts_f32): the all-reduce of the sharded Lloyd iteration, the same
+ * bits on every rank and in the oracle's n_shards mode -- which ncclAllReduce(sum) does not promise. */
+int at_comm_allgather_f32(at_ctx* ctx, void* nccl_comm, const float* part, float* parts, int64_t count, void* stream);
+int at_comm_allreduce_ordered_f32(at_ctx* ctx, void* nccl_comm, const float* part, float* parts_scratch, float* out,
+                                  int64_t count, void* stream);
 
 /* at_split_clusters_host on DEVICE buffers (hassign [k], centroids [k][d], both updated in place), same bits:
  * one workgroup regenerates the mt19937(1234) stream in LDS and runs the cyclic acceptance scans, so a Lloyd

@@ -197,3 +197,54 @@ def test_rccl_collectives_execute_with_one_rank(be):
     assert out["gather"] and out["scatter"] and out["bits"] and out["flag"] is True
     assert out["sizes"] == [77] and out["f64"] == 1.25
     assert out["gather_train"] and out["scatter_train"]
+
+
+def _rccl_cabi_worker(q):
+    import ctypes
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    from audio_tokens_amd import _lib
+    from audio_tokens_amd.backend import default_backend
+    torch.cuda.set_device(0)
+    be = default_backend()
+    # the communicator is the CALLER's: a one-rank one made with the same RCCL the wrappers will find (loaded globally
+    # first, so that their lookup among the process's symbols resolves to this copy)
+    rccl = ctypes.CDLL("/opt/rocm/lib/librccl.so", mode=ctypes.RTLD_GLOBAL)
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        n = 100003
+        part = torch.randn(n, device="cuda")
+        parts = torch.full((n,), -1.0, device="cuda")
+        out = torch.full((n,), -2.0, device="cuda")
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        ptr = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+        _lib.check(be.lib.at_comm_allgather_f32(be.ctx.handle, comm, ptr(part), ptr(parts), n, stream))
+        _lib.check(be.lib.at_comm_allreduce_ordered_f32(be.ctx.handle, comm, ptr(part), ptr(parts), ptr(out), n, stream))
+        torch.cuda.synchronize()
+        q.put({"gather": bool(torch.equal(parts, part)), "reduce": bool(torch.equal(out, part))})
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)
+
+
+def test_rccl_wrappers_of_the_c_abi_with_one_rank(be):
+    """at_comm_allgather_f32 / at_comm_allreduce_ordered_f32 (the exchange for hosts without torch.distributed) on a
+    one-rank communicator the test creates with RCCL itself: with one rank both must return the rank's own part."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_cabi_worker, args=(q,))
+    p.start()
+    out = q.get(timeout=300)
+    p.join(60)
+    assert p.exitcode == 0
+    assert out == {"gather": True, "reduce": True}
