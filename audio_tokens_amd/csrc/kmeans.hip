@@ -572,11 +572,16 @@ __global__ void __launch_bounds__(1024) long_ranksort_kernel(uint32_t* __restric
 }
 
 // sorted_ids[p] = the cluster of position p (k for the trailing bucket of invalid ids)
-__global__ void __launch_bounds__(WG) segment_ids_kernel(const uint32_t* __restrict__ offsets, int k, uint32_t* __restrict__ sorted_ids) {
+// (and, when the caller wants the member order too, its copy out of the workspace in the same pass)
+__global__ void __launch_bounds__(WG) segment_ids_kernel(const uint32_t* __restrict__ offsets, int k, uint32_t* __restrict__ sorted_ids,
+                                                         const uint32_t* __restrict__ order, uint32_t* __restrict__ order_out) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * (WG / 64) + (threadIdx.x >> 6);
     if (c > k) return;
-    for (uint32_t p = offsets[c] + lane; p < offsets[c + 1]; p += 64) sorted_ids[p] = (uint32_t)c;
+    for (uint32_t p = offsets[c] + lane; p < offsets[c + 1]; p += 64) {
+        sorted_ids[p] = (uint32_t)c;
+        if (order_out) order_out[p] = order[p];
+    }
 }
 
 __global__ void __launch_bounds__(WG) centroid_finalize_kernel(const float* __restrict__ sums_parts,
@@ -794,14 +799,20 @@ int accum_buckets(at_ctx* ctx, const float* x, int64_t n, int d, const int64_t* 
         // the copies below read the long clusters' segments, which the side stream writes
         AT_HIP(hipStreamWaitEvent(stream, ctx->side_ev[1], 0));
     }
-    if (order_out && n > 0)
+    // A caller that wants the member order gets the long clusters' segments too, and those are written on the side
+    // stream: its work is waited for BEFORE the order leaves the workspace (round 1 queued the copy first and waited
+    // right after it -- the same wait, one statement too late).
+    const bool wants_order = (order_out || sorted_ids_out) && n > 0;
+    if (have_long && wants_order) AT_HIP(hipStreamWaitEvent(stream, ctx->side_ev[1], 0));
+    if (order_out && n > 0 && !sorted_ids_out)
         AT_HIP(hipMemcpyAsync(order_out, order, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream));
-    if (sorted_ids_out && n > 0) {
-        hipLaunchKernelGGL(segment_ids_kernel, dim3((k + 1 + WG / 64 - 1) / (WG / 64)), dim3(WG), 0, stream, offsets, k, sorted_ids_out);
+    if (sorted_ids_out && n > 0) {   // (the segments [offsets[0], offsets[k+1]) cover every position: the copy rides along)
+        hipLaunchKernelGGL(segment_ids_kernel, dim3((k + 1 + WG / 64 - 1) / (WG / 64)), dim3(WG), 0, stream, offsets, k, sorted_ids_out,
+                           order, order_out);
         AT_LAUNCH_CHECK();
     }
-    if (have_long) {
-        if (ctx->defer_join && !(order_out || sorted_ids_out)) ctx->join_pending = 1;
+    if (have_long && !wants_order) {
+        if (ctx->defer_join) ctx->join_pending = 1;
         else AT_HIP(hipStreamWaitEvent(stream, ctx->side_ev[1], 0));
     }
     return AT_OK;
