@@ -34,6 +34,8 @@ SIGNATURES = {
     "at_workspace_bytes": (_i64, [_vp]),
     "at_debug_set": (_i32, [_vp, _c.c_char_p, _i32]),
     "at_debug_get": (_i32, [_vp, _c.c_char_p, _c.POINTER(_i32)]),
+    "at_diag_errors": (_i32, [_c.POINTER(_i64), _c.POINTER(_i32), _c.POINTER(_i64), _c.POINTER(_i32), _c.c_char_p, _i32, _i32]),
+    "at_debug_leave_error_pending": (_i32, []),
     "at_rand_perm_mt19937": (_i32, [_i64, _i64, _vp]),
     "at_rand_perm_prefix_mt19937": (_i32, [_i64, _i64, _i64, _vp]),
     "at_rand_perm_prefix_device": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp]),

@@ -138,6 +138,17 @@ class HipBackend(HostHelpers):
         _lib.check(self.lib.at_debug_get(self.ctx.handle, name.encode(), ctypes.byref(v)))
         return int(v.value)
 
+    def diag_errors(self, reset=False) -> dict:
+        """What the library met and did not treat as its own failure (include/at_debug.h: at_diag_errors): HIP errors
+        found pending in the calling thread in front of one of its launches, and failures it tolerates by design."""
+        stale, tol = ctypes.c_int64(0), ctypes.c_int64(0)
+        sc, tc = ctypes.c_int(0), ctypes.c_int(0)
+        where = ctypes.create_string_buffer(512)
+        _lib.check(self.lib.at_diag_errors(ctypes.byref(stale), ctypes.byref(sc), ctypes.byref(tol), ctypes.byref(tc),
+                                           where, 512, 1 if reset else 0))
+        return {"stale_seen": int(stale.value), "stale_last_code": int(sc.value), "tolerated": int(tol.value),
+                "tolerated_last_code": int(tc.value), "where": where.value.decode()}
+
     # -- plumbing --------------------------------------------------------------------------
     def _stream(self) -> _vp:
         return _vp(torch.cuda.current_stream(self.device).cuda_stream)

@@ -1110,21 +1110,13 @@ int launch_mfma(at_ctx* ctx, const float* x, int64_t n, const float* c, int k, i
     const size_t img_bytes = sizeof(float) * (size_t)ntiles * tile_floats(D, NA);
     float* img = static_cast<float*>(at_ws(ctx, WS_CENT_IMG, img_bytes, stream));
     if (!img) return AT_E_NOMEM;
-    hipLaunchKernelGGL(prep_centroids_kernel, dim3(ntiles), dim3(WG), 0, stream, c, k, D, D, NA, img);
-    AT_LAUNCH_CHECK();
+    AT_LAUNCH(prep_centroids_kernel, dim3(ntiles), dim3(WG), 0, stream, c, k, D, D, NA, img);
     const size_t lds = 2 * sizeof(float) * tile_floats(D, NA);
     const int64_t rows_per_wg = 4 * 32 * NB;
     const int64_t grid = (n + rows_per_wg - 1) / rows_per_wg;
-    static bool attr_set = false;
-    if (!attr_set) {
-        AT_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&assign_mfma_kernel<D, NB, NA, DMA, WPS, SPEC>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((assign_mfma_kernel<D, NB, NA, DMA, WPS, SPEC>), dim3((unsigned)grid), dim3(WG), lds,
+    { const int rcl_ = at_raise_lds(ctx, reinterpret_cast<const void*>(&assign_mfma_kernel<D, NB, NA, DMA, WPS, SPEC>), lds); if (rcl_) return rcl_; }
+    AT_LAUNCH((assign_mfma_kernel<D, NB, NA, DMA, WPS, SPEC>), dim3((unsigned)grid), dim3(WG), lds,
                        stream, x, (long)n, img, ntiles, reinterpret_cast<long*>(ids), dist);
-    AT_LAUNCH_CHECK();
     return AT_OK;
 }
 
@@ -1137,19 +1129,12 @@ static int launch_anyd(at_ctx* ctx, const float* x, int64_t n, int d, const floa
     const size_t tile_f = (size_t)tile_rows(NA) * DC * nchunks + CN_PAD;
     float* img = static_cast<float*>(at_ws(ctx, WS_CENT_IMG, sizeof(float) * ntiles * tile_f, stream));
     if (!img) return AT_E_NOMEM;
-    hipLaunchKernelGGL(prep_centroids_chunked_kernel, dim3(ntiles), dim3(WG), 0, stream, c, k, d, nchunks, NA, img);
-    AT_LAUNCH_CHECK();
+    AT_LAUNCH(prep_centroids_chunked_kernel, dim3(ntiles), dim3(WG), 0, stream, c, k, d, nchunks, NA, img);
     const size_t lds = 2 * sizeof(float) * (tile_rows(NA) * DC + CN_PAD);
-    static bool attr_set = false;
-    if (!attr_set) {
-        AT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&assign_mfma_anyd_kernel<NB, NA, WPS>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    { const int rcl_ = at_raise_lds(ctx, reinterpret_cast<const void*>(&assign_mfma_anyd_kernel<NB, NA, WPS>), lds); if (rcl_) return rcl_; }
     const int64_t rows_per_wg = 4 * 32 * NB;
-    hipLaunchKernelGGL((assign_mfma_anyd_kernel<NB, NA, WPS>), dim3((unsigned)((n + rows_per_wg - 1) / rows_per_wg)),
+    AT_LAUNCH((assign_mfma_anyd_kernel<NB, NA, WPS>), dim3((unsigned)((n + rows_per_wg - 1) / rows_per_wg)),
                        dim3(WG), lds, stream, x, (long)n, d, nchunks, img, ntiles, reinterpret_cast<long*>(ids), dist);
-    AT_LAUNCH_CHECK();
     return AT_OK;
 }
 
@@ -1166,9 +1151,8 @@ extern "C" int at_assign_f32(at_ctx* ctx, const float* x, int64_t n, int d, cons
     AT_HIP(hipSetDevice(ctx->device));
 
     if (n < 20) {
-        hipLaunchKernelGGL(assign_small_kernel, dim3(1), dim3(32), 0, stream, x, (int)n, d, c, k,
+        AT_LAUNCH(assign_small_kernel, dim3(1), dim3(32), 0, stream, x, (int)n, d, c, k,
                            reinterpret_cast<long*>(ids), dist);
-        AT_LAUNCH_CHECK();
         return AT_OK;
     }
 
@@ -1199,11 +1183,9 @@ extern "C" int at_assign_f32(at_ctx* ctx, const float* x, int64_t n, int d, cons
 
     float* cn = static_cast<float*>(at_ws(ctx, WS_CENT_IMG, sizeof(float) * (size_t)k, stream));
     if (!cn) return AT_E_NOMEM;
-    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((k + WG - 1) / WG), dim3(WG), 0, stream, c, k, d, cn);
-    AT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(assign_generic_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0,
+    AT_LAUNCH(row_sqnorm_kernel, dim3((k + WG - 1) / WG), dim3(WG), 0, stream, c, k, d, cn);
+    AT_LAUNCH(assign_generic_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0,
                        stream, x, (long)n, d, c, cn, k, reinterpret_cast<long*>(ids), dist);
-    AT_LAUNCH_CHECK();
     return AT_OK;
 }
 
@@ -1225,40 +1207,26 @@ extern "C" int at_assign_hinted_f32(at_ctx* ctx, const float* x, int64_t n, int 
         const int ntiles = (k + tile_rows(NA) - 1) / tile_rows(NA);
         float* img = static_cast<float*>(at_ws(ctx, WS_CENT_IMG, sizeof(float) * (size_t)ntiles * tile_floats(D, NA), stream));
         if (!img) return AT_E_NOMEM;
-        hipLaunchKernelGGL(prep_centroids_kernel, dim3(ntiles), dim3(WG), 0, stream, c, k, D, D, NA, img);
-        AT_LAUNCH_CHECK();
+        AT_LAUNCH(prep_centroids_kernel, dim3(ntiles), dim3(WG), 0, stream, c, k, D, D, NA, img);
         const size_t lds = 2 * sizeof(float) * tile_floats(D, NA);
-        static bool attr_set = false;
-        if (!attr_set) {
-            AT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&assign_mfma_hinted_kernel<D, NB, NA>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
+        { const int rcl_ = at_raise_lds(ctx, reinterpret_cast<const void*>(&assign_mfma_hinted_kernel<D, NB, NA>), lds); if (rcl_) return rcl_; }
         const int64_t rows_per_wg = 4 * 32 * NB;
-        hipLaunchKernelGGL((assign_mfma_hinted_kernel<D, NB, NA>), dim3((unsigned)((n + rows_per_wg - 1) / rows_per_wg)),
+        AT_LAUNCH((assign_mfma_hinted_kernel<D, NB, NA>), dim3((unsigned)((n + rows_per_wg - 1) / rows_per_wg)),
                            dim3(WG), lds, stream, x, (long)n, c, k, img, ntiles, order,
                            reinterpret_cast<const long*>(hint_ids), hint_sorted, reinterpret_cast<long*>(ids), dist);
-        AT_LAUNCH_CHECK();
         return AT_OK;
     }
     constexpr int D = 128, NB = 1, NA = 2;
     const int ntiles = (k + tile_rows(NA) - 1) / tile_rows(NA);
     float* img = static_cast<float*>(at_ws(ctx, WS_CENT_IMG, sizeof(float) * (size_t)ntiles * tile_floats(D, NA), stream));
     if (!img) return AT_E_NOMEM;
-    hipLaunchKernelGGL(prep_centroids_kernel, dim3(ntiles), dim3(WG), 0, stream, c, k, D, D, NA, img);
-    AT_LAUNCH_CHECK();
+    AT_LAUNCH(prep_centroids_kernel, dim3(ntiles), dim3(WG), 0, stream, c, k, D, D, NA, img);
     const size_t lds = 2 * sizeof(float) * tile_floats(D, NA);
-    static bool attr_set128 = false;
-    if (!attr_set128) {
-        AT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&assign_mfma_hinted_kernel<D, NB, NA>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set128 = true;
-    }
+    { const int rcl_ = at_raise_lds(ctx, reinterpret_cast<const void*>(&assign_mfma_hinted_kernel<D, NB, NA>), lds); if (rcl_) return rcl_; }
     const int64_t rows_per_wg = 4 * 32 * NB;
-    hipLaunchKernelGGL((assign_mfma_hinted_kernel<D, NB, NA>), dim3((unsigned)((n + rows_per_wg - 1) / rows_per_wg)),
+    AT_LAUNCH((assign_mfma_hinted_kernel<D, NB, NA>), dim3((unsigned)((n + rows_per_wg - 1) / rows_per_wg)),
                        dim3(WG), lds, stream, x, (long)n, c, k, img, ntiles, order,
                        reinterpret_cast<const long*>(hint_ids), hint_sorted, reinterpret_cast<long*>(ids), dist);
-    AT_LAUNCH_CHECK();
     return AT_OK;
 }
 
@@ -1281,8 +1249,7 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
     // fp32 image (one tile per group, NA = 1: 32 rows, then |c|^2 at [0,32) and indices at [128,160)): built
     // only where the fp32 sweep runs -- without the filter, or for its long-list redo
     auto prep_fp32_image = [&]() -> int {
-        hipLaunchKernelGGL(prep_centroids_perm_kernel, dim3(ng), dim3(WG), 0, stream, c, k, D, cperm, kp, 1, img);
-        AT_LAUNCH_CHECK();
+        AT_LAUNCH(prep_centroids_perm_kernel, dim3(ng), dim3(WG), 0, stream, c, k, D, cperm, kp, 1, img);
         return AT_OK;
     };
     if (!filter) {
@@ -1320,7 +1287,7 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
             rcp = at_filter_resolve_pending(ctx, true);   // the synchronous form reads its words at once: keep the order
             if (rcp) return rcp;
         }
-        rcp = at_filter_use_slot_events(ctx, slot);
+        rcp = at_filter_use_slot(ctx, slot);
         if (rcp) return rcp;
         unsigned* misc = static_cast<unsigned*>(at_ws(ctx, WS_FILTER_MISC, 1024, stream));
         const size_t lstride = at_amb_stride(n);   // five arrays of 64 sub-lists: list | sorted | order | hints | aux
@@ -1369,10 +1336,14 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
         ctx->filter_listed += listed;
         ctx->filter_tiles += host_misc[4];
         ctx->filter_refined += host_misc[5];
-        float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, ctx->filter_ev[0], ctx->filter_ev[1]) == hipSuccess) {
-            ctx->filter_ms += ms;
-            ctx->filter_launches++;
+        {
+            at_filter_slot& spare = ctx->fring[AT_FILTER_RING];
+            float ms = 0.0f;
+            if (spare.timed && AT_HIP_TOLERATE(hipEventElapsedTime(&ms, spare.ev[0], spare.ev[1])) == hipSuccess) {
+                ctx->filter_ms += ms;
+                ctx->filter_launches++;
+            }
+            spare.timed = 0;
         }
         if ((int64_t)listed * 16 <= n) ctx->filter_force_sync = 0;   // the data behave again
         if (listed == 0) return AT_OK;
@@ -1403,14 +1374,13 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
     }
     // d = 64: register-staged A operand (no LDS); AT_PRUNE_KERNEL=0 selects the LDS-DMA form (A/B aid)
     if (ctx->dbg.prune_kernel != 0 && D == 64 && NB <= 2)
-        hipLaunchKernelGGL((assign_mfma_pruned_reg_kernel<D, NB>), dim3((unsigned)((n2 + rows_per_wg - 1) / rows_per_wg)),
+        AT_LAUNCH((assign_mfma_pruned_reg_kernel<D, NB>), dim3((unsigned)((n2 + rows_per_wg - 1) / rows_per_wg)),
                            dim3(64), 0, stream, x, (long)n2, img, ng, order2, hint2, bd, mask, ngw,
                            reinterpret_cast<long*>(ids), dist);
     else
-        hipLaunchKernelGGL((assign_mfma_pruned_kernel<D, NB>), dim3((unsigned)((n2 + rows_per_wg - 1) / rows_per_wg)),
+        AT_LAUNCH((assign_mfma_pruned_kernel<D, NB>), dim3((unsigned)((n2 + rows_per_wg - 1) / rows_per_wg)),
                            dim3(64), lds, stream, x, (long)n2, img, ng, order2, hint2, bd, mask, ngw,
                            reinterpret_cast<long*>(ids), dist);
-    AT_LAUNCH_CHECK();
     return AT_OK;
 }
 
@@ -1462,9 +1432,16 @@ extern "C" int at_prune_mask_f32(at_ctx* ctx, const float* x, int64_t n, int d, 
     return at_prune_prepass(ctx, x, n, d, c, k, order, hint_sorted, dmin, ng, bd, mask, ngw, mode, stream);
 }
 
-// fp16-split filter: rows swept / rows handed to the fp32 redo since the last reset.
-// Folds the statistics words an asynchronous exact call left in pinned memory into the totals.
-int at_filter_use_slot_events(at_ctx* ctx, int slot) {
+// The statistics ring of the asynchronous exact calls (at_internal.h: at_filter_slot).
+// Life of a slot: claimed by at_filter_use_slot (timed = 0) -> the sweep records ev[0], ev[1] around its kernel only
+// under the switch filter_timing and then sets timed = 1 -> the call queues the copy of its statistics words and
+// records `copied` -> pushed (fring_count++) -> at_filter_resolve_pending reads the words once `copied` has
+// completed and the two timing events only if timed is set.  hipEventElapsedTime on an event that was never
+// recorded returns hipErrorInvalidResourceHandle and leaves it pending in the thread (the error round 2's launch
+// check then blamed on the next kernel launch): it is not called on such events any more, and its result is
+// consumed where it is tolerated.
+int at_filter_use_slot(at_ctx* ctx, int slot) {
+    AT_REQUIRE(slot >= 0 && slot <= AT_FILTER_RING, "at_filter_use_slot: slot %d out of range", slot);
     if (!ctx->filter_host_misc) {
         AT_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->filter_host_misc), (size_t)(AT_FILTER_RING + 1) * 128 * sizeof(unsigned),
                              hipHostMallocDefault));
@@ -1472,11 +1449,8 @@ int at_filter_use_slot_events(at_ctx* ctx, int slot) {
     }
     at_filter_slot& fs = ctx->fring[slot];
     if (!fs.copied) AT_HIP(hipEventCreateWithFlags(&fs.copied, hipEventDisableTiming));
-    for (int i = 0; i < 2; i++)
-        if (!fs.ev[i])  // no system-scope release at the event: it would charge an L2 write-back to the kernel
-            AT_HIP(hipEventCreateWithFlags(&fs.ev[i], hipEventDisableSystemFence));
-    ctx->filter_ev[0] = fs.ev[0];
-    ctx->filter_ev[1] = fs.ev[1];
+    fs.timed = 0;
+    ctx->filter_slot = slot;
     return AT_OK;
 }
 
@@ -1487,7 +1461,7 @@ int at_filter_resolve_pending(at_ctx* ctx, bool wait_all) {
             AT_HIP(hipEventSynchronize(fs.copied));
         } else {
             const hipError_t q = hipEventQuery(fs.copied);
-            if (q == hipErrorNotReady) break;
+            if (q == hipErrorNotReady) break;   // an answer, not a failure (and the one code HIP does not keep pending)
             AT_HIP(q);
         }
         const unsigned* hm = fs.host_misc;
@@ -1497,10 +1471,13 @@ int at_filter_resolve_pending(at_ctx* ctx, bool wait_all) {
         ctx->filter_listed += listed;
         ctx->filter_tiles += hm[4];
         ctx->filter_refined += hm[5];
-        float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, fs.ev[0], fs.ev[1]) == hipSuccess) {
-            ctx->filter_ms += ms;
-            ctx->filter_launches++;
+        if (fs.timed) {   // (both events were recorded before `copied`, on the same stream: they have completed)
+            float ms = 0.0f;
+            if (AT_HIP_TOLERATE(hipEventElapsedTime(&ms, fs.ev[0], fs.ev[1])) == hipSuccess) {
+                ctx->filter_ms += ms;
+                ctx->filter_launches++;
+            }
+            fs.timed = 0;
         }
         if ((int64_t)listed * 16 > fs.rows) ctx->filter_force_sync = 1;
         ctx->fring_head = (ctx->fring_head + 1) % AT_FILTER_RING;
@@ -1550,6 +1527,8 @@ extern "C" int at_filter_probe_f32(at_ctx* ctx, const float* x, int64_t n, int d
     uint32_t* list = static_cast<uint32_t*>(at_ws(ctx, WS_FILTER_LIST, sizeof(uint32_t) * 5 * lstride, stream));
     if (!bd || !mask || !misc || !list) return AT_E_NOMEM;
     int rc = at_prune_prepass(ctx, x, n, d, c, k, order, hint_sorted, dmin, ng, bd, mask, ngw, 0, stream);
+    if (rc) return rc;
+    rc = at_filter_use_slot(ctx, AT_FILTER_RING);   // (a call outside the ring: the spare slot)
     if (rc) return rc;
     rc = at_filter_sweep(ctx, x, n, d, c, k, order, cperm, ng, bd, mask, ngw, 1, ids, misc, list,
                          list + 4 * lstride, approx, nullptr, nullptr, nullptr, nullptr, at_amb_cap(n), stream);

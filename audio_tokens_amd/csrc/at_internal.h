@@ -5,6 +5,8 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <tuple>
+#include <utility>
 
 #include "../../include/audio_tokens_amd.h"
 #include "../../include/at_debug.h"
@@ -62,9 +64,10 @@ enum at_ws_slot {
 // the ring is full or a query asks for the totals.
 constexpr int AT_FILTER_RING = 64;
 struct at_filter_slot {
-    unsigned* host_misc;   // pinned, 64 words
+    unsigned* host_misc;   // pinned, 128 words
     hipEvent_t copied;     // behind the D2H copy of the words
-    hipEvent_t ev[2];      // around the stage-1 kernel
+    hipEvent_t ev[2];      // around the stage-1 kernel (created on first use, and only under the switch filter_timing)
+    int timed;             // both of ev[] were recorded by the call that holds this slot (else they are not read)
     int64_t rows;
 };
 
@@ -85,6 +88,7 @@ struct at_debug {
     int visit_bits;       // AT_VISIT_BITS       distance bits of the visiting-order key (0..8; default 8)
     int filter_stats;     // AT_FILTER_STATS     1 = the sweeps count accumulators / tiles for at_prune_stats, at_filter_stats
     int accum_buckets;    // AT_ACCUM_BUCKETS    0 = member lists by radix sort (the only form for k > 16 384)
+    int filter_timing;    // AT_FILTER_TIMING    1 = exact calls bracket their stage-1 kernel with two timing events (bench.py; off in the product)
 };
 
 struct at_ctx {
@@ -104,7 +108,7 @@ struct at_ctx {
     int n_cus;             // multiProcessorCount of the device (read once in at_create)
     int rs_orig, rs_new;  // what WS_RESAMPLE_TAPS currently holds
     int64_t filter_rows, filter_listed;  // fp16-split filter: rows swept / rows handed to the fp32 redo
-    hipEvent_t filter_ev[2];             // around the stage-1 kernel of exact calls (created on first use)
+    int filter_slot;                     // the ring slot (or AT_FILTER_RING, the spare) the sweep being queued belongs to
     double filter_ms;                    // summed stage-1 kernel time, over filter_launches launches
     int64_t filter_launches;
     int64_t filter_tiles, filter_refined;
@@ -129,7 +133,18 @@ struct at_ctx {
     const unsigned* img16_misc;
     int img16_k, img16_d, img16_ng, img16_trusted;
     int img16_misc_clean;   // the words behind max|c|^2 in img16_misc are still zero (nobody has swept since they were cleared)
+    // dynamic-LDS limits raised so far ON THIS DEVICE (hipFuncAttributeMaxDynamicSharedMemorySize is per device: a
+    // process-wide "already raised" flag would leave the second device of a process at the default limit)
+    struct { const void* func; size_t bytes; } lds_raised[48];
+    int n_lds_raised;
+    hipEvent_t sum_ev;        // behind the last at_sum_f32 launch (its partials and counter are per context)
+    hipStream_t sum_stream;
+    int sum_used;
 };
+
+// makes launches of `func` with `bytes` of dynamic LDS legal on the context's device (at most one runtime call per
+// kernel and size step; nothing below the default limit)
+int at_raise_lds(at_ctx* ctx, const void* func, size_t bytes);
 
 int at_fail(int code, const char* fmt, ...);
 // randperm.hip: resident prefix of the mt19937(seed) stream (6722 blocks of 624 outputs: covers the 4 194 304
@@ -140,20 +155,75 @@ int at_mt_cached_draws(at_ctx* ctx, uint32_t seed, hipStream_t stream, const uin
 // Returns a device buffer of at least `bytes` for `slot` (contents undefined after growth).
 void* at_ws(at_ctx* ctx, int slot, size_t bytes, hipStream_t stream);
 
+// ---- error handling ----------------------------------------------------------------------------------------
+// On ROCm 7.2 the error a failing HIP call leaves behind is STICKY: it stays in the calling thread until somebody
+// calls hipGetLastError(), whatever succeeds in between (measured: tools/probes/event_probe.hip; hipErrorNotReady is
+// the one code that is not kept).  Round 2 checked launches with a bare hipGetLastError() behind them, which
+// therefore reported whatever any earlier call of this thread -- the library's, torch's, rocPRIM's -- had failed
+// with and nobody had consumed ("kernel launch failed: invalid resource handle" out of a launch that was fine).
+// Rules since round 3:
+//   * every call whose failure is an error goes through AT_HIP: the call's OWN return code decides;
+//   * every launch goes through AT_LAUNCH: hipLaunchKernel's OWN return code decides, never the thread's last error;
+//   * a call whose failure is tolerated goes through AT_HIP_TOLERATE, which consumes the sticky error the failure
+//     left (so it cannot surface in the host application's, or rocPRIM's, next hipGetLastError) and counts it;
+//   * an error that is already pending when a launch is about to be made is not this library's launch failing:
+//     it is consumed, counted and remembered (at_diag_*), and fails the call only under the switch strict_errors
+//     ("stale error from an earlier call"), which the test-suite turns on.
+struct at_diag_counters {
+    long stale_seen;          // errors found pending in front of a launch
+    int stale_last_code;
+    const char* stale_last_file;
+    int stale_last_line;
+    long tolerated;           // failing calls whose failure was tolerated (AT_HIP_TOLERATE)
+    int tolerated_last_code;
+    const char* tolerated_last_file;
+    int tolerated_last_line;
+};
+extern at_diag_counters g_at_diag;          // host.cpp (one per process; the counts are diagnostics, not state)
+extern int g_at_strict_errors;              // host.cpp: switch strict_errors (AT_STRICT_ERRORS), process-wide
+
+hipError_t at_hip_tolerated(hipError_t e, const char* file, int line);
+// returns hipSuccess, or -- strict mode -- the pending error
+hipError_t at_stale_check(const char* file, int line);
+
 #define AT_HIP(expr)                                                                       \
     do {                                                                                   \
         hipError_t e_ = (expr);                                                            \
-        if (e_ != hipSuccess)                                                              \
+        if (e_ != hipSuccess) {                                                            \
+            (void)hipGetLastError(); /* reported here: do not leave it pending as well */  \
             return at_fail(AT_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
                            __FILE__, __LINE__);                                            \
+        }                                                                                  \
     } while (0)
 
-#define AT_LAUNCH_CHECK()                                                                  \
-    do {                                                                                   \
-        hipError_t e_ = hipGetLastError();                                                 \
-        if (e_ != hipSuccess)                                                              \
-            return at_fail(AT_E_HIP, "kernel launch failed: %s (%s:%d)",                   \
-                           hipGetErrorString(e_), __FILE__, __LINE__);                     \
+// the call's code, with the sticky copy of a failure consumed and counted
+#define AT_HIP_TOLERATE(expr) at_hip_tolerated((expr), __FILE__, __LINE__)
+
+// Kernel launch by hipLaunchKernel, whose return value is this launch's own verdict.  Arguments are converted to the
+// kernel's parameter types first (what the <<< >>> stub does), then passed by address.
+template <typename... KArgs, typename... Args>
+static inline hipError_t at_launch_raw(void (*kern)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t stream,
+                                       Args&&... args) {
+    static_assert(sizeof...(KArgs) == sizeof...(Args), "at_launch_raw: argument count does not match the kernel's");
+    std::tuple<KArgs...> params{static_cast<KArgs>(std::forward<Args>(args))...};
+    void* ptrs[sizeof...(KArgs) > 0 ? sizeof...(KArgs) : 1];
+    int i = 0;
+    std::apply([&](auto&... p) { ((ptrs[i++] = const_cast<void*>(static_cast<const void*>(&p))), ...); }, params);
+    return hipLaunchKernel(reinterpret_cast<const void*>(kern), grid, block, ptrs, lds, stream);
+}
+
+#define AT_LAUNCH(kern, grid, block, lds, stream, ...)                                                   \
+    do {                                                                                                  \
+        hipError_t s_ = at_stale_check(__FILE__, __LINE__);                                               \
+        if (s_ != hipSuccess)                                                                             \
+            return at_fail(AT_E_HIP, "stale error from an earlier call (pending before the launch of %s): %s (%s:%d)", \
+                           #kern, hipGetErrorString(s_), __FILE__, __LINE__);                             \
+        hipError_t e_ = at_launch_raw(kern, grid, block, lds, stream, __VA_ARGS__);                       \
+        if (e_ != hipSuccess) {                                                                           \
+            (void)hipGetLastError();                                                                      \
+            return at_fail(AT_E_HIP, "launch of %s failed: %s (%s:%d)", #kern, hipGetErrorString(e_),     \
+                           __FILE__, __LINE__);                                                           \
+        }                                                                                                 \
     } while (0)
 
 #define AT_REQUIRE(cond, ...)                                  \
@@ -201,8 +271,9 @@ int at_filter_coarse(at_ctx* ctx, const float* x, int64_t n, int d, const float*
 
 // wait_all: fold every pending slot (blocking); otherwise only those whose copy has already arrived
 int at_filter_resolve_pending(at_ctx* ctx, bool wait_all);
-// makes ctx->filter_ev name the timing events of ring slot `slot` (created on first use)
-int at_filter_use_slot_events(at_ctx* ctx, int slot);
+// the sweep queued next belongs to ring slot `slot` (AT_FILTER_RING: the spare, for calls outside the ring); creates
+// what the slot needs on first use and marks its timing events as not recorded
+int at_filter_use_slot(at_ctx* ctx, int slot);
 
 static inline bool at_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -7,8 +7,9 @@
 // CPU restatement's n_shards mode the tests compare with -- gets the same bits; an ncclAllReduce(sum) does not promise an order, hence all-gather +
 // the fixed-order sum of at_sum_parts_f32 / at_centroid_finalize_f32.
 //
-// RCCL is looked up at run time (dlopen of librccl.so, or whatever copy the process has loaded already -- a host that
-// created the communicator has one): the library itself keeps no link-time dependency on it.
+// RCCL is looked up at run time among the libraries the process has ALREADY loaded (a host that created the
+// communicator has one); nothing new is ever loaded -- a second copy of RCCL must not be handed another copy's
+// communicator -- and the library itself keeps no link-time dependency on it.  No loaded copy: AT_E_COMM.
 #include <dlfcn.h>
 
 #include <mutex>
@@ -35,10 +36,17 @@ Rccl& rccl() {
     std::lock_guard<std::mutex> g(m);
     if (!r.tried) {
         r.tried = true;
-        void* h = dlopen(nullptr, RTLD_NOW);                       // a copy the process already holds (e.g. torch's)
-        if (!h || !dlsym(h, "ncclAllGather")) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!h || !dlsym(h, "ncclAllGather")) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!h || !dlsym(h, "ncclAllGather")) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        // Only a copy of RCCL that the process has loaded ALREADY is bound: the communicator the caller hands over was
+        // created by some copy, and calling into another one with it is undefined behaviour.  The global scope first
+        // (a host linked against RCCL), then -- without loading anything, RTLD_NOLOAD -- the sonames a copy loaded
+        // with RTLD_LOCAL goes by (torch's bundled librccl.so is loaded that way, as a dependency of libtorch_hip.so).
+        void* h = dlopen(nullptr, RTLD_NOW);
+        if (h && !dlsym(h, "ncclAllGather")) h = nullptr;
+        for (const char* name : {"librccl.so.1", "librccl.so", "librccl.so.2"})
+            if (!h) {
+                h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+                if (h && !dlsym(h, "ncclAllGather")) h = nullptr;
+            }
         if (h) {
             r.all_gather = reinterpret_cast<allgather_fn>(dlsym(h, "ncclAllGather"));
             r.comm_count = reinterpret_cast<count_fn>(dlsym(h, "ncclCommCount"));
@@ -59,7 +67,7 @@ extern "C" {
 int at_comm_allgather_f32(at_ctx* ctx, void* nccl_comm, const float* part, float* parts, int64_t count, void* stream_) {
     AT_REQUIRE(ctx && nccl_comm && part && parts && count > 0, "at_comm_allgather_f32: bad arguments");
     Rccl& r = rccl();
-    if (!r.all_gather) return at_fail(AT_E_COMM, "at_comm_allgather_f32: RCCL (librccl.so) is not available in this process");
+    if (!r.all_gather) return at_fail(AT_E_COMM, "at_comm_allgather_f32: no RCCL is loaded in this process (the communicator's own copy is looked up, nothing is loaded)");
     AT_HIP(hipSetDevice(ctx->device));
     const int rc = r.all_gather(part, parts, (size_t)count, NCCL_FLOAT32, nccl_comm, static_cast<hipStream_t>(stream_));
     if (rc != 0) return at_fail(AT_E_COMM, "at_comm_allgather_f32: ncclAllGather failed: %s", r.error_string ? r.error_string(rc) : "?");
@@ -72,7 +80,7 @@ int at_comm_allreduce_ordered_f32(at_ctx* ctx, void* nccl_comm, const float* par
                                   int64_t count, void* stream_) {
     AT_REQUIRE(ctx && nccl_comm && part && parts_scratch && out && count > 0, "at_comm_allreduce_ordered_f32: bad arguments");
     Rccl& r = rccl();
-    if (!r.all_gather || !r.comm_count) return at_fail(AT_E_COMM, "at_comm_allreduce_ordered_f32: RCCL (librccl.so) is not available in this process");
+    if (!r.all_gather || !r.comm_count) return at_fail(AT_E_COMM, "at_comm_allreduce_ordered_f32: no RCCL is loaded in this process (the communicator's own copy is looked up, nothing is loaded)");
     int n_ranks = 0;
     const int rcq = r.comm_count(nccl_comm, &n_ranks);
     if (rcq != 0 || n_ranks < 1) return at_fail(AT_E_COMM, "at_comm_allreduce_ordered_f32: ncclCommCount failed");

@@ -1140,8 +1140,7 @@ size_t at_filter_group_bytes(int d) { return group_bytes(d); }
 int at_amb_compact(at_ctx* ctx, const unsigned* misc, unsigned amb_cap, const uint32_t* list, const uint32_t* aux,
                    uint32_t* list_out, uint32_t* aux_out, hipStream_t stream) {
     (void)ctx;
-    hipLaunchKernelGGL(amb_compact_kernel, dim3(256), dim3(WG), 0, stream, misc, amb_cap, list, aux, list_out, aux_out);
-    AT_LAUNCH_CHECK();
+    AT_LAUNCH(amb_compact_kernel, dim3(256), dim3(WG), 0, stream, misc, amb_cap, list, aux, list_out, aux_out);
     return AT_OK;
 }
 
@@ -1178,8 +1177,7 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
     } else {
         ctx->img16_c = nullptr;
         AT_HIP(hipMemsetAsync(misc, 0, 128 * sizeof(unsigned), stream));  // max|c|^2, statistics, sub-list lengths
-        hipLaunchKernelGGL(prep_centroids_f16_kernel, dim3(ng), dim3(WG), 0, stream, c, k, d, cperm, img, misc);
-        AT_LAUNCH_CHECK();
+        AT_LAUNCH(prep_centroids_f16_kernel, dim3(ng), dim3(WG), 0, stream, c, k, d, cperm, img, misc);
     }
     float ta = 0.0f, tb = 0.0f, ra = 0.0f, rb = 0.0f;
     filter_tau(d, &ta, &tb);
@@ -1204,15 +1202,20 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
         blk_stats = static_cast<uint4*>(at_ws(ctx, WS_FILTER_BLKSTATS, (size_t)n_wg * sizeof(uint4), stream));
         if (!blk_stats) return AT_E_NOMEM;
     }
-    if (collect) {  // exact calls: time the kernel for at_filter_stats
-        if (!ctx->filter_ev[0]) {   // (a caller that did not pick a ring slot: the spare pair)
-            int rce = at_filter_use_slot_events(ctx, AT_FILTER_RING);
-            if (rce) return rce;
-        }
-        AT_HIP(hipEventRecord(ctx->filter_ev[0], stream));
+    // exact calls under the switch filter_timing (bench.py): two timing events around the kernel, read by
+    // at_filter_resolve_pending / the synchronous form once the call's statistics have arrived.  The product leaves
+    // the switch off: no event is recorded and none is read.
+    at_filter_slot& tslot = ctx->fring[(ctx->filter_slot >= 0 && ctx->filter_slot <= AT_FILTER_RING) ? ctx->filter_slot : AT_FILTER_RING];
+    const bool timed = collect && ctx->dbg.filter_timing != 0;
+    tslot.timed = 0;
+    if (timed) {
+        for (int i = 0; i < 2; i++)
+            if (!tslot.ev[i])  // no system-scope release at the event: it would charge an L2 write-back to the kernel
+                AT_HIP(hipEventCreateWithFlags(&tslot.ev[i], hipEventDisableSystemFence));
+        AT_HIP(hipEventRecord(tslot.ev[0], stream));
     }
 #define AT_FILTER_LAUNCH(DD, NBB, GG, FF, GRID)                                                                      \
-    hipLaunchKernelGGL((assign_f16filter_kernel<DD, NBB, GG, FF>), GRID, dim3(64), 0, stream, x, (long)n, img, ng, order, \
+    AT_LAUNCH((assign_f16filter_kernel<DD, NBB, GG, FF>), GRID, dim3(64), 0, stream, x, (long)n, img, ng, order, \
                        bd, mask, ngw, misc, ta, tb, ra, rb, screen, collect, reinterpret_cast<long*>(ids), amb_list,      \
                        amb_aux, approx_out, fp, blk_stats, amb_cap)
     // exact calls (collect) and guess generators are separate instantiations: the guess path's code
@@ -1227,12 +1230,12 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
         else if (collect) AT_FILTER_LAUNCH(64, 4, false, false, grid);
         else AT_FILTER_LAUNCH(64, 4, true, false, grid);
     } else if (one_tile) {
-        hipLaunchKernelGGL((assign_f16filter_kernel<64, 1, false, true, 4>), grid, dim3(64), 0, stream, x, (long)n, img, ng,
+        AT_LAUNCH((assign_f16filter_kernel<64, 1, false, true, 4>), grid, dim3(64), 0, stream, x, (long)n, img, ng,
                            order, bd, mask, ngw, misc, ta, tb, ra, rb, screen, collect, reinterpret_cast<long*>(ids),
                            amb_list, amb_aux, approx_out, fp, blk_stats, amb_cap);
     } else {
         if (wps3) {
-            hipLaunchKernelGGL((assign_f16filter_kernel<64, 2, false, true, 3>), grid, dim3(64), 0, stream, x, (long)n, img, ng,
+            AT_LAUNCH((assign_f16filter_kernel<64, 2, false, true, 3>), grid, dim3(64), 0, stream, x, (long)n, img, ng,
                                order, bd, mask, ngw, misc, ta, tb, ra, rb, screen, collect, reinterpret_cast<long*>(ids),
                                amb_list, amb_aux, approx_out, fp, blk_stats, amb_cap);
         } else if (fused) AT_FILTER_LAUNCH(64, 2, false, true, grid);
@@ -1240,11 +1243,12 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
         else AT_FILTER_LAUNCH(64, 2, true, false, grid);
     }
 #undef AT_FILTER_LAUNCH
-    AT_LAUNCH_CHECK();
-    if (collect) AT_HIP(hipEventRecord(ctx->filter_ev[1], stream));
+    if (timed) {
+        AT_HIP(hipEventRecord(tslot.ev[1], stream));
+        tslot.timed = 1;
+    }
     if (blk_stats) {
-        hipLaunchKernelGGL(filter_stats_reduce_kernel, dim3(1), dim3(1024), 0, stream, blk_stats, n_wg, fused ? fp.stats : nullptr, misc);
-        AT_LAUNCH_CHECK();
+        AT_LAUNCH(filter_stats_reduce_kernel, dim3(1), dim3(1024), 0, stream, blk_stats, n_wg, fused ? fp.stats : nullptr, misc);
     }
     return AT_OK;
 }
@@ -1256,21 +1260,19 @@ int at_exact_dist_rows(at_ctx* ctx, const float* x, int64_t n, int d, const floa
     const dim3 grid((unsigned)((n + WG - 1) / WG));
     if (order && hint_sorted && bd) {  // guesses with their pre-pass distances available
         if (d == 64)
-            hipLaunchKernelGGL(exact_dist_visit_kernel<64>, grid, dim3(WG), 0, stream, x, (long)n, c, k, order,
+            AT_LAUNCH(exact_dist_visit_kernel<64>, grid, dim3(WG), 0, stream, x, (long)n, c, k, order,
                                hint_sorted, bd, reinterpret_cast<const long*>(ids), dist);
         else
-            hipLaunchKernelGGL(exact_dist_visit_kernel<128>, grid, dim3(WG), 0, stream, x, (long)n, c, k, order,
+            AT_LAUNCH(exact_dist_visit_kernel<128>, grid, dim3(WG), 0, stream, x, (long)n, c, k, order,
                                hint_sorted, bd, reinterpret_cast<const long*>(ids), dist);
-        AT_LAUNCH_CHECK();
         return AT_OK;
     }
     if (d == 64)
-        hipLaunchKernelGGL(exact_dist_rows_kernel<64>, grid, dim3(WG), 0, stream, x, (long)n, c, k,
+        AT_LAUNCH(exact_dist_rows_kernel<64>, grid, dim3(WG), 0, stream, x, (long)n, c, k,
                            reinterpret_cast<const long*>(ids), dist);
     else
-        hipLaunchKernelGGL(exact_dist_rows_kernel<128>, grid, dim3(WG), 0, stream, x, (long)n, c, k,
+        AT_LAUNCH(exact_dist_rows_kernel<128>, grid, dim3(WG), 0, stream, x, (long)n, c, k,
                            reinterpret_cast<const long*>(ids), dist);
-    AT_LAUNCH_CHECK();
     return AT_OK;
 }
 
@@ -1284,9 +1286,8 @@ int at_filter_gather_ambiguous(at_ctx* ctx, uint32_t* amb_list, uint32_t* amb_so
     void* tmp = at_ws(ctx, WS_SORT_TMP, tmp_bytes, stream);
     if (!tmp) return AT_E_NOMEM;
     AT_HIP(rocprim::radix_sort_keys(tmp, tmp_bytes, amb_list, amb_sorted, (size_t)m_valid, 0, 32, stream));
-    hipLaunchKernelGGL(gather_ambiguous_kernel, dim3((unsigned)((m + WG - 1) / WG)), dim3(WG), 0, stream, amb_sorted,
+    AT_LAUNCH(gather_ambiguous_kernel, dim3((unsigned)((m + WG - 1) / WG)), dim3(WG), 0, stream, amb_sorted,
                        (long)m, (long)m_valid, order, reinterpret_cast<const long*>(ids), order_amb, hint_amb);
-    AT_LAUNCH_CHECK();
     return AT_OK;
 }
 
@@ -1300,12 +1301,11 @@ int at_filter_redo_rows(at_ctx* ctx, const float* x, int d, const float* c, int 
     if (m <= 0) return AT_OK;   // m = list length, or (with count_dev) the number of workgroups to launch
     AT_REQUIRE(ng <= 512, "at_filter_redo_rows: ng > 512");
     if (d == 64)
-        hipLaunchKernelGGL(exact_rows_kernel<64>, dim3((unsigned)m), dim3(WG), 0, stream, x, c, k, list, order, cperm, dmin,
+        AT_LAUNCH(exact_rows_kernel<64>, dim3((unsigned)m), dim3(WG), 0, stream, x, c, k, list, order, cperm, dmin,
                            ng, misc, aux, reinterpret_cast<long*>(ids), dist, count_dev, amb_cap);
     else
-        hipLaunchKernelGGL(exact_rows_kernel<128>, dim3((unsigned)m), dim3(WG), 0, stream, x, c, k, list, order, cperm,
+        AT_LAUNCH(exact_rows_kernel<128>, dim3((unsigned)m), dim3(WG), 0, stream, x, c, k, list, order, cperm,
                            dmin, ng, misc, aux, reinterpret_cast<long*>(ids), dist, count_dev, amb_cap);
-    AT_LAUNCH_CHECK();
     return AT_OK;
 }
 
@@ -1315,8 +1315,7 @@ int at_group_min_dist_f16(at_ctx* ctx, const float* c, int k, int d, const int32
     unsigned* misc = static_cast<unsigned*>(at_ws(ctx, WS_FILTER_MISC, 1024, stream));  // word 0 = max|c|^2, as the sweep wants it
     if (!img || !misc) return AT_E_NOMEM;
     AT_HIP(hipMemsetAsync(misc, 0, 128 * sizeof(unsigned), stream));   // max|c|^2 and, for the sweep that follows, its counters
-    hipLaunchKernelGGL(prep_centroids_f16_kernel, dim3(ng), dim3(WG), 0, stream, c, k, d, cperm, img, misc);
-    AT_LAUNCH_CHECK();
+    AT_LAUNCH(prep_centroids_f16_kernel, dim3(ng), dim3(WG), 0, stream, c, k, d, cperm, img, misc);
     ctx->img16_c = c; ctx->img16_cperm = cperm; ctx->img16_k = k; ctx->img16_d = d; ctx->img16_ng = ng;
     ctx->img16_misc = misc;
     ctx->img16_misc_clean = 1;
@@ -1331,14 +1330,13 @@ int at_group_min_dist_f16(at_ctx* ctx, const float* c, int k, int d, const int32
     const float eps_b = 0.5f * tb * 1.001f + rb;
     const dim3 grid((unsigned)((k + 63) / 64), (unsigned)((ng + DMIN_GPW - 1) / DMIN_GPW));
     if (d == 64 && three)
-        hipLaunchKernelGGL((group_min_dist_f16_kernel<64, true>), grid, dim3(64), 0, stream, c, k, img, ng, misc, eps_a, eps_b, dmin);
+        AT_LAUNCH((group_min_dist_f16_kernel<64, true>), grid, dim3(64), 0, stream, c, k, img, ng, misc, eps_a, eps_b, dmin);
     else if (d == 64)
-        hipLaunchKernelGGL((group_min_dist_f16_kernel<64, false>), grid, dim3(64), 0, stream, c, k, img, ng, misc, eps_a, eps_b, dmin);
+        AT_LAUNCH((group_min_dist_f16_kernel<64, false>), grid, dim3(64), 0, stream, c, k, img, ng, misc, eps_a, eps_b, dmin);
     else if (three)
-        hipLaunchKernelGGL((group_min_dist_f16_kernel<128, true>), grid, dim3(64), 0, stream, c, k, img, ng, misc, eps_a, eps_b, dmin);
+        AT_LAUNCH((group_min_dist_f16_kernel<128, true>), grid, dim3(64), 0, stream, c, k, img, ng, misc, eps_a, eps_b, dmin);
     else
-        hipLaunchKernelGGL((group_min_dist_f16_kernel<128, false>), grid, dim3(64), 0, stream, c, k, img, ng, misc, eps_a, eps_b, dmin);
-    AT_LAUNCH_CHECK();
+        AT_LAUNCH((group_min_dist_f16_kernel<128, false>), grid, dim3(64), 0, stream, c, k, img, ng, misc, eps_a, eps_b, dmin);
     return AT_OK;
 }
 
@@ -1348,12 +1346,11 @@ int at_exact_dist_todo(at_ctx* ctx, const float* x, int64_t n, int d, const floa
     (void)ctx;
     const dim3 grid((unsigned)((n + WG - 1) / WG));
     if (d == 64)
-        hipLaunchKernelGGL(exact_dist_todo_kernel<64>, grid, dim3(WG), 0, stream, x, (long)n, c, k,
+        AT_LAUNCH(exact_dist_todo_kernel<64>, grid, dim3(WG), 0, stream, x, (long)n, c, k,
                            reinterpret_cast<const long*>(ids), dist);
     else
-        hipLaunchKernelGGL(exact_dist_todo_kernel<128>, grid, dim3(WG), 0, stream, x, (long)n, c, k,
+        AT_LAUNCH(exact_dist_todo_kernel<128>, grid, dim3(WG), 0, stream, x, (long)n, c, k,
                            reinterpret_cast<const long*>(ids), dist);
-    AT_LAUNCH_CHECK();
     return AT_OK;
 }
 
@@ -1378,12 +1375,11 @@ int at_filter_coarse(at_ctx* ctx, const float* x, int64_t n, int d, const float*
     if (!img || !img_m || !perm_m || !misc) return AT_E_NOMEM;
     ctx->img16_c = nullptr;
     ctx->img16_misc_clean = 0;
-    hipLaunchKernelGGL(iota_pad_kernel, dim3((ngm * 32 + WG - 1) / WG), dim3(WG), 0, stream, perm_m, ng, ngm * 32);
+    AT_LAUNCH(iota_pad_kernel, dim3((ngm * 32 + WG - 1) / WG), dim3(WG), 0, stream, perm_m, ng, ngm * 32);
     AT_HIP(hipMemsetAsync(misc, 0, 64 * sizeof(unsigned), stream));
-    hipLaunchKernelGGL(prep_centroids_f16_kernel, dim3(ngm), dim3(WG), 0, stream, means, ng, d, perm_m, img_m,
+    AT_LAUNCH(prep_centroids_f16_kernel, dim3(ngm), dim3(WG), 0, stream, means, ng, d, perm_m, img_m,
                        static_cast<unsigned*>(nullptr));
-    hipLaunchKernelGGL(prep_centroids_f16_kernel, dim3(ng), dim3(WG), 0, stream, c, k, d, cperm, img, misc);
-    AT_LAUNCH_CHECK();
+    AT_LAUNCH(prep_centroids_f16_kernel, dim3(ng), dim3(WG), 0, stream, c, k, d, cperm, img, misc);
     float ta = 0.0f, tb = 0.0f, ra = 0.0f, rb = 0.0f;
     filter_tau(d, &ta, &tb);
     filter_rho(d, &ra, &rb);
@@ -1399,13 +1395,12 @@ int at_filter_coarse(at_ctx* ctx, const float* x, int64_t n, int d, const float*
     uint32_t* no_list = nullptr;
     float* no_approx = nullptr;
     if (d == 128)
-        hipLaunchKernelGGL((assign_f16filter_kernel<128, 2, true, false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, x,
+        AT_LAUNCH((assign_f16filter_kernel<128, 2, true, false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, x,
                            (long)n, img, ng, no_order, no_bd, no_mask, ngw, misc, ta, tb, ra, rb, 1, 0,
                            reinterpret_cast<long*>(ids), no_list, no_list, no_approx, fp, static_cast<uint4*>(nullptr), 0u);
     else
-        hipLaunchKernelGGL((assign_f16filter_kernel<64, 4, true, false>), dim3((unsigned)((n + 127) / 128)), dim3(64), 0, stream, x,
+        AT_LAUNCH((assign_f16filter_kernel<64, 4, true, false>), dim3((unsigned)((n + 127) / 128)), dim3(64), 0, stream, x,
                            (long)n, img, ng, no_order, no_bd, no_mask, ngw, misc, ta, tb, ra, rb, 1, 0,
                            reinterpret_cast<long*>(ids), no_list, no_list, no_approx, fp, static_cast<uint4*>(nullptr), 0u);
-    AT_LAUNCH_CHECK();
     return AT_OK;
 }

@@ -18,6 +18,31 @@
 
 static thread_local std::string g_last_error;
 
+at_diag_counters g_at_diag = {};
+int g_at_strict_errors = 0;
+
+hipError_t at_hip_tolerated(hipError_t e, const char* file, int line) {
+    if (e != hipSuccess && e != hipErrorNotReady) {   // (hipErrorNotReady is an answer, not a failure, and is not kept)
+        (void)hipGetLastError();                      // the sticky copy of this failure: consumed here, where it is known
+        g_at_diag.tolerated++;
+        g_at_diag.tolerated_last_code = (int)e;
+        g_at_diag.tolerated_last_file = file;
+        g_at_diag.tolerated_last_line = line;
+    }
+    return e;
+}
+
+hipError_t at_stale_check(const char* file, int line) {
+    const hipError_t s = hipPeekAtLastError();
+    if (s == hipSuccess) return hipSuccess;
+    (void)hipGetLastError();
+    g_at_diag.stale_seen++;
+    g_at_diag.stale_last_code = (int)s;
+    g_at_diag.stale_last_file = file;
+    g_at_diag.stale_last_line = line;
+    return g_at_strict_errors ? s : hipSuccess;
+}
+
 int at_fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -44,6 +69,7 @@ const DebugField kDebugFields[] = {
     {"accum_buckets", "AT_ACCUM_BUCKETS", &at_debug::accum_buckets, 1},
     {"filter_stats", "AT_FILTER_STATS", &at_debug::filter_stats, 0},
     {"visit_bits", "AT_VISIT_BITS", &at_debug::visit_bits, 8},
+    {"filter_timing", "AT_FILTER_TIMING", &at_debug::filter_timing, 0},
 };
 }  // namespace
 
@@ -53,6 +79,10 @@ int at_version(void) { return AT_VERSION; }
 
 int at_debug_set(at_ctx* ctx, const char* name, int value) {
     AT_REQUIRE(ctx && name, "at_debug_set: null argument");
+    if (std::strcmp(name, "strict_errors") == 0) {   // process-wide (the launch macro has no context at hand)
+        g_at_strict_errors = value != 0;
+        return AT_OK;
+    }
     for (const DebugField& f : kDebugFields)
         if (std::strcmp(f.name, name) == 0) {
             ctx->dbg.*(f.field) = value;
@@ -63,6 +93,10 @@ int at_debug_set(at_ctx* ctx, const char* name, int value) {
 
 int at_debug_get(const at_ctx* ctx, const char* name, int* value) {
     AT_REQUIRE(ctx && name && value, "at_debug_get: null argument");
+    if (std::strcmp(name, "strict_errors") == 0) {
+        *value = g_at_strict_errors;
+        return AT_OK;
+    }
     for (const DebugField& f : kDebugFields)
         if (std::strcmp(f.name, name) == 0) {
             *value = ctx->dbg.*(f.field);
@@ -72,6 +106,33 @@ int at_debug_get(const at_ctx* ctx, const char* name, int* value) {
 }
 
 const char* at_last_error(void) { return g_last_error.c_str(); }
+
+int at_diag_errors(int64_t* stale_seen, int* stale_last_code, int64_t* tolerated, int* tolerated_last_code, char* where,
+                   int where_bytes, int reset) {
+    if (stale_seen) *stale_seen = g_at_diag.stale_seen;
+    if (stale_last_code) *stale_last_code = g_at_diag.stale_last_code;
+    if (tolerated) *tolerated = g_at_diag.tolerated;
+    if (tolerated_last_code) *tolerated_last_code = g_at_diag.tolerated_last_code;
+    if (where && where_bytes > 0)
+        snprintf(where, (size_t)where_bytes, "stale: %s:%d; tolerated: %s:%d",
+                 g_at_diag.stale_last_file ? g_at_diag.stale_last_file : "-", g_at_diag.stale_last_line,
+                 g_at_diag.tolerated_last_file ? g_at_diag.tolerated_last_file : "-", g_at_diag.tolerated_last_line);
+    if (reset) g_at_diag = at_diag_counters{};
+    return AT_OK;
+}
+
+// Test hook: leaves a failed HIP call's error pending in the calling thread, the way a call that swallows its
+// return code does (hipEventElapsedTime on two events that were never recorded: hipErrorInvalidResourceHandle).
+int at_debug_leave_error_pending(void) {
+    hipEvent_t a = nullptr, b = nullptr;
+    AT_HIP(hipEventCreate(&a));
+    AT_HIP(hipEventCreate(&b));
+    float ms = 0.0f;
+    const hipError_t e = hipEventElapsedTime(&ms, a, b);   // deliberately not consumed
+    const hipError_t d0 = hipEventDestroy(a), d1 = hipEventDestroy(b);   // (successful calls do not clear it)
+    (void)d0; (void)d1;
+    return e == hipSuccess ? at_fail(AT_E_INVALID, "at_debug_leave_error_pending: the call did not fail") : AT_OK;
+}
 
 int at_create(int device, at_ctx** out) {
     AT_REQUIRE(out != nullptr, "at_create: out is null");
@@ -88,37 +149,41 @@ int at_create(int device, at_ctx** out) {
     if (!c) return at_fail(AT_E_NOMEM, "at_create: out of host memory");
     std::memset(c, 0, sizeof *c);
     c->device = device;
+    c->filter_slot = AT_FILTER_RING;
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     for (const DebugField& f : kDebugFields) {   // the only place the environment is read
         const char* e = std::getenv(f.env);
         c->dbg.*(f.field) = e ? std::atoi(e) : f.def;
     }
+    if (const char* e = std::getenv("AT_STRICT_ERRORS")) g_at_strict_errors = std::atoi(e) != 0;
     *out = c;
     return AT_OK;
 }
 
 void at_destroy(at_ctx* ctx) {
     if (!ctx) return;
+    // (a destructor has nobody to report to: failures are tolerated, and consumed so that they do not stay pending)
     int prev = 0;
-    (void)hipGetDevice(&prev);
-    (void)hipSetDevice(ctx->device);
-    (void)hipDeviceSynchronize();
+    (void)AT_HIP_TOLERATE(hipGetDevice(&prev));
+    (void)AT_HIP_TOLERATE(hipSetDevice(ctx->device));
+    (void)AT_HIP_TOLERATE(hipDeviceSynchronize());
     for (int i = 0; i < WS_NSLOTS; i++)
-        if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+        if (ctx->ws[i]) (void)AT_HIP_TOLERATE(hipFree(ctx->ws[i]));
     for (int i = 0; i < 2; i++)
-        if (ctx->side_ev[i]) (void)hipEventDestroy(ctx->side_ev[i]);
-    for (int s = 0; s <= AT_FILTER_RING; s++) {   // (ctx->filter_ev only aliases a slot's pair)
+        if (ctx->side_ev[i]) (void)AT_HIP_TOLERATE(hipEventDestroy(ctx->side_ev[i]));
+    for (int s = 0; s <= AT_FILTER_RING; s++) {
         at_filter_slot& fs = ctx->fring[s];
-        if (fs.copied) (void)hipEventDestroy(fs.copied);
+        if (fs.copied) (void)AT_HIP_TOLERATE(hipEventDestroy(fs.copied));
         for (int i = 0; i < 2; i++)
-            if (fs.ev[i]) (void)hipEventDestroy(fs.ev[i]);
+            if (fs.ev[i]) (void)AT_HIP_TOLERATE(hipEventDestroy(fs.ev[i]));
     }
-    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
-    if (ctx->mt_ready) (void)hipEventDestroy(ctx->mt_ready);
-    if (ctx->filter_host_misc) (void)hipHostFree(ctx->filter_host_misc);
+    if (ctx->side_stream) (void)AT_HIP_TOLERATE(hipStreamDestroy(ctx->side_stream));
+    if (ctx->mt_ready) (void)AT_HIP_TOLERATE(hipEventDestroy(ctx->mt_ready));
+    if (ctx->sum_ev) (void)AT_HIP_TOLERATE(hipEventDestroy(ctx->sum_ev));
+    if (ctx->filter_host_misc) (void)AT_HIP_TOLERATE(hipHostFree(ctx->filter_host_misc));
     std::free(ctx->fb_user_copy);
     std::free(ctx->any_user_copy);
-    (void)hipSetDevice(prev);
+    (void)AT_HIP_TOLERATE(hipSetDevice(prev));
     delete ctx;
 }
 
@@ -131,6 +196,19 @@ int64_t at_workspace_bytes(const at_ctx* ctx) {
 
 }  // extern "C"
 
+int at_raise_lds(at_ctx* ctx, const void* func, size_t bytes) {
+    if (bytes <= 32 * 1024) return AT_OK;
+    const int cap = (int)(sizeof ctx->lds_raised / sizeof ctx->lds_raised[0]);
+    int slot = -1;
+    for (int i = 0; i < ctx->n_lds_raised; i++)
+        if (ctx->lds_raised[i].func == func) { slot = i; break; }
+    if (slot >= 0 && ctx->lds_raised[slot].bytes >= bytes) return AT_OK;
+    AT_HIP(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (slot < 0 && ctx->n_lds_raised < cap) slot = ctx->n_lds_raised++;
+    if (slot >= 0) { ctx->lds_raised[slot].func = func; ctx->lds_raised[slot].bytes = bytes; }
+    return AT_OK;   // (a full table only means the attribute is set again next time)
+}
+
 void* at_ws(at_ctx* ctx, int slot, size_t bytes, hipStream_t stream) {
     if (bytes == 0) bytes = 16;
     if (ctx->ws_bytes[slot] >= bytes) return ctx->ws[slot];
@@ -138,16 +216,20 @@ void* at_ws(at_ctx* ctx, int slot, size_t bytes, hipStream_t stream) {
     // caller's second stream (the slots are per purpose, not per stream): drain the device before freeing.
     if (ctx->ws[slot]) {
         (void)stream;
-        if (hipDeviceSynchronize() != hipSuccess) return nullptr;
-        (void)hipFree(ctx->ws[slot]);
+        const hipError_t es = AT_HIP_TOLERATE(hipDeviceSynchronize());
+        if (es != hipSuccess) {
+            at_fail(AT_E_HIP, "workspace slot %d: hipDeviceSynchronize failed before regrowth: %s", slot, hipGetErrorString(es));
+            return nullptr;
+        }
+        (void)AT_HIP_TOLERATE(hipFree(ctx->ws[slot]));
         ctx->ws[slot] = nullptr;
         ctx->ws_bytes[slot] = 0;
     }
     size_t want = bytes + bytes / 8;  // a little slack so slowly growing batches do not thrash
     want = (want + 255) & ~size_t(255);
     void* p = nullptr;
-    if (hipMalloc(&p, want) != hipSuccess) {
-        if (hipMalloc(&p, bytes) != hipSuccess) {
+    if (AT_HIP_TOLERATE(hipMalloc(&p, want)) != hipSuccess) {
+        if (AT_HIP_TOLERATE(hipMalloc(&p, bytes)) != hipSuccess) {
             at_fail(AT_E_NOMEM, "workspace slot %d: hipMalloc(%zu) failed", slot, bytes);
             return nullptr;
         }

@@ -165,6 +165,19 @@ constexpr int LONG_PER_THREAD = (LONG_CHUNK + LONG_LOADERS - 1) / LONG_LOADERS;
 constexpr int EARLY_MAX = 16;       // long clusters whose member lists come from the ordered compaction
 constexpr int EARLY_ROWS = 4096;    // rows per workgroup of the ordered compaction
 
+// WS_LONG_PRED, in ints: [0] number of long clusters the last call saw (the next call's early set, capped at
+// EARLY_MAX), [1 .. EARLY_MAX] their ids, then k generation marks ("summed early in call `gen`").  One definition for
+// both call sites: round 2 raised EARLY_MAX from 8 to 16 and left the marks at offset 16, on top of the last id.
+struct LongPred {
+    int* pred_n;
+    int* pred;
+    unsigned* done;
+    static constexpr size_t MARKS_AT = 1 + EARLY_MAX;
+    static size_t bytes(int k) { return (MARKS_AT + (size_t)k) * sizeof(int); }
+    explicit LongPred(int* pw) : pred_n(pw), pred(pw + 1), done(reinterpret_cast<unsigned*>(pw + MARKS_AT)) {}
+};
+static_assert(LongPred::MARKS_AT >= 1 + EARLY_MAX, "the generation marks must start behind the last predicted cluster id");
+
 // early != 0: list `slot` of the early lists (cluster cluster_of[slot], members early_offsets[slot] ..); marks the
 // cluster done[c] = gen.  early == 0: the regular pass over all clusters after the sort; records every long cluster
 // in pred (the next call's early set) and skips those the early pass has already summed.
@@ -628,8 +641,10 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // One launch: every workgroup leaves its partial sum, the last one to arrive (a counter that it also puts back to
-// zero) adds the partials up in index order with the same tree the separate second kernel of round 1 used -- the
-// same bits, one launch less in every Lloyd iteration.
+// zero) adds the partials up in index order.  The result is a fixed function of (v, n): the grid is a function of n
+// alone and every tree below is fixed, so repeated calls and all ranks agree bit for bit.  (It is NOT the partition
+// round 1's two-kernel form used: the grid was capped at 256 / 1024 workgroups in round 2.  The objective it feeds is
+// the one statistic the contract holds to a tolerance)
 __global__ void __launch_bounds__(WG) sum_kernel(const float* __restrict__ v, long n, double* __restrict__ partial,
                                                  unsigned* __restrict__ ticket, double* __restrict__ out) {
     __shared__ double sh[WG / 64];
@@ -723,15 +738,8 @@ int accum_buckets(at_ctx* ctx, const float* x, int64_t n, int d, const int64_t* 
     const bool long_ok = d % 4 == 0 && al;
     const uint32_t long_list = long_ok ? 2048u : UINT32_MAX;   // (without the sliced kernel every list is a short one)
     const size_t lds1 = ((size_t)k + 1) * 4, lds3 = 2 * lds1;
-    static size_t attr1 = 0, attr3 = 0;
-    if (lds1 > 48 * 1024 && lds1 > attr1) {
-        AT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-        attr1 = lds1;
-    }
-    if (lds3 > 48 * 1024 && lds3 > attr3) {
-        AT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-        attr3 = lds3;
-    }
+    { const int rcl_ = at_raise_lds(ctx, reinterpret_cast<const void*>(&bucket_count_kernel), lds1); if (rcl_) return rcl_; }
+    { const int rcl_ = at_raise_lds(ctx, reinterpret_cast<const void*>(&bucket_scatter_kernel), lds3); if (rcl_) return rcl_; }
     const long* idl = reinterpret_cast<const long*>(ids);
     // rows per workgroup of the count / scatter passes: enough workgroups to fill the chip at small n (each pays
     // three passes over the k bins), 4096 rows at large n
@@ -740,11 +748,9 @@ int accum_buckets(at_ctx* ctx, const float* x, int64_t n, int d, const int64_t* 
     rpb = (rpb + WG - 1) / WG * WG;
     const int nbk = (int)((n + rpb - 1) / rpb);
     if (n > 0) {
-        hipLaunchKernelGGL(bucket_count_kernel, dim3(nbk), dim3(WG), lds1, stream, idl, (long)n, k, rpb, bcounts);
-        AT_LAUNCH_CHECK();
+        AT_LAUNCH(bucket_count_kernel, dim3(nbk), dim3(WG), lds1, stream, idl, (long)n, k, rpb, bcounts);
     }
-    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, bcounts, k, long_list, offsets, cursor, longs);
-    AT_LAUNCH_CHECK();
+    AT_LAUNCH(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, bcounts, k, long_list, offsets, cursor, longs);
     const bool have_long = long_ok && n > (int64_t)long_list;
     if (have_long) {
         if (!ctx->side_stream) {
@@ -756,28 +762,25 @@ int accum_buckets(at_ctx* ctx, const float* x, int64_t n, int d, const int64_t* 
         hipStream_t ss = ctx->side_stream;
         AT_HIP(hipEventRecord(ctx->side_ev[0], stream));          // offsets / longs are ready
         AT_HIP(hipStreamWaitEvent(ss, ctx->side_ev[0], 0));
-        hipLaunchKernelGGL(early_count_kernel, dim3(nblk), dim3(WG), 0, ss, idl, (long)n, longs + 1, longs, nblk, blockcnt);
-        hipLaunchKernelGGL(early_scan_kernel, dim3(1), dim3(1024), 0, ss, blockcnt, nblk, blockbase, blockbase + (size_t)EARLY_MAX * nblk);
-        hipLaunchKernelGGL(early_write_kernel, dim3(nblk), dim3(WG), 0, ss, idl, (long)n, longs + 1, longs, nblk, blockbase,
+        AT_LAUNCH(early_count_kernel, dim3(nblk), dim3(WG), 0, ss, idl, (long)n, longs + 1, longs, nblk, blockcnt);
+        AT_LAUNCH(early_scan_kernel, dim3(1), dim3(1024), 0, ss, blockcnt, nblk, blockbase, blockbase + (size_t)EARLY_MAX * nblk);
+        AT_LAUNCH(early_write_kernel, dim3(nblk), dim3(WG), 0, ss, idl, (long)n, longs + 1, longs, nblk, blockbase,
                            nullptr, order, offsets);
-        hipLaunchKernelGGL(centroid_accum_long_kernel, dim3(EARLY_MAX, d / 4), dim3(WG), 0, ss, x, d, order, offsets, long_list,
+        AT_LAUNCH(centroid_accum_long_kernel, dim3(EARLY_MAX, d / 4), dim3(WG), 0, ss, x, d, order, offsets, long_list,
                            sums, counts, k, 0, longs, nullptr, nullptr, 0u, 0, EARLY_MAX);
-        AT_LAUNCH_CHECK();
     }
     if (n > 0) {
-        hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nbk), dim3(WG), lds3, stream, idl, (long)n, k, rpb, cursor, order);
-        hipLaunchKernelGGL(member_sort_kernel, dim3((k + 1 + WG / 64 - 1) / (WG / 64)), dim3(WG), 0, stream, order, offsets, k, 2048u);
-        AT_LAUNCH_CHECK();
+        AT_LAUNCH(bucket_scatter_kernel, dim3(nbk), dim3(WG), lds3, stream, idl, (long)n, k, rpb, cursor, order);
+        AT_LAUNCH(member_sort_kernel, dim3((k + 1 + WG / 64 - 1) / (WG / 64)), dim3(WG), 0, stream, order, offsets, k, 2048u);
     }
     if (have_long) {
         // more than EARLY_MAX long clusters (rare): the rest were scattered; rank-sort them, then their sums
         hipStream_t ss = ctx->side_stream;
         AT_HIP(hipEventRecord(ctx->side_ev[0], stream));          // scattered segments are ready
         AT_HIP(hipStreamWaitEvent(ss, ctx->side_ev[0], 0));
-        hipLaunchKernelGGL(long_ranksort_kernel, dim3(16), dim3(1024), 0, ss, order, offsets, longs, scratch);
-        hipLaunchKernelGGL(centroid_accum_long_kernel, dim3(16, d / 4), dim3(WG), 0, ss, x, d, order, offsets, long_list,
+        AT_LAUNCH(long_ranksort_kernel, dim3(16), dim3(1024), 0, ss, order, offsets, longs, scratch);
+        AT_LAUNCH(centroid_accum_long_kernel, dim3(16, d / 4), dim3(WG), 0, ss, x, d, order, offsets, long_list,
                            sums, counts, k, 0, longs, nullptr, nullptr, 0u, EARLY_MAX, 0x7fffffff);
-        AT_LAUNCH_CHECK();
         AT_HIP(hipEventRecord(ctx->side_ev[1], ss));
     }
     int vec = 1;
@@ -789,12 +792,11 @@ int accum_buckets(at_ctx* ctx, const float* x, int64_t n, int d, const int64_t* 
     // lists of 1025 .. 2048 rows that no local sort took (member_sort_kernel's capacity is 2048: none) -- and, when the
     // sliced kernel cannot run (d % 4 != 0), lists of any length: those need the sorted order too
     if (vec == 4)
-        hipLaunchKernelGGL(centroid_accum_kernel<4>, grid, dim3(WG), 0, stream, x, d, order, offsets, k, slabs, long_list, sums, counts);
+        AT_LAUNCH(centroid_accum_kernel<4>, grid, dim3(WG), 0, stream, x, d, order, offsets, k, slabs, long_list, sums, counts);
     else if (vec == 2)
-        hipLaunchKernelGGL(centroid_accum_kernel<2>, grid, dim3(WG), 0, stream, x, d, order, offsets, k, slabs, long_list, sums, counts);
+        AT_LAUNCH(centroid_accum_kernel<2>, grid, dim3(WG), 0, stream, x, d, order, offsets, k, slabs, long_list, sums, counts);
     else
-        hipLaunchKernelGGL(centroid_accum_kernel<1>, grid, dim3(WG), 0, stream, x, d, order, offsets, k, slabs, long_list, sums, counts);
-    AT_LAUNCH_CHECK();
+        AT_LAUNCH(centroid_accum_kernel<1>, grid, dim3(WG), 0, stream, x, d, order, offsets, k, slabs, long_list, sums, counts);
     if ((order_out || sorted_ids_out) && have_long) {
         // the copies below read the long clusters' segments, which the side stream writes
         AT_HIP(hipStreamWaitEvent(stream, ctx->side_ev[1], 0));
@@ -807,9 +809,8 @@ int accum_buckets(at_ctx* ctx, const float* x, int64_t n, int d, const int64_t* 
     if (order_out && n > 0 && !sorted_ids_out)
         AT_HIP(hipMemcpyAsync(order_out, order, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream));
     if (sorted_ids_out && n > 0) {   // (the segments [offsets[0], offsets[k+1]) cover every position: the copy rides along)
-        hipLaunchKernelGGL(segment_ids_kernel, dim3((k + 1 + WG / 64 - 1) / (WG / 64)), dim3(WG), 0, stream, offsets, k, sorted_ids_out,
+        AT_LAUNCH(segment_ids_kernel, dim3((k + 1 + WG / 64 - 1) / (WG / 64)), dim3(WG), 0, stream, offsets, k, sorted_ids_out,
                            order, order_out);
-        AT_LAUNCH_CHECK();
     }
     if (have_long && !wants_order) {
         if (ctx->defer_join) ctx->join_pending = 1;
@@ -832,14 +833,13 @@ int at_gather_rows_f32(at_ctx* ctx, const float* x, int d, const int32_t* idx, i
     AT_HIP(hipSetDevice(ctx->device));
     if (d % 4 == 0 && at_aligned16(x) && at_aligned16(out)) {
         const long total = m * (d / 4);
-        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + WG - 1) / WG)), dim3(WG), 0,
+        AT_LAUNCH(gather_rows_kernel, dim3((unsigned)((total + WG - 1) / WG)), dim3(WG), 0,
                            stream, x, d / 4, idx, (long)m, out);
     } else {
         const long total = m * d;
-        hipLaunchKernelGGL(gather_rows_scalar_kernel, dim3((unsigned)((total + WG - 1) / WG)), dim3(WG),
+        AT_LAUNCH(gather_rows_scalar_kernel, dim3((unsigned)((total + WG - 1) / WG)), dim3(WG),
                            0, stream, x, d, idx, (long)m, out);
     }
-    AT_LAUNCH_CHECK();
     return AT_OK;
 }
 
@@ -876,15 +876,16 @@ int at_centroid_accum_f32(at_ctx* ctx, const float* x, int64_t n, int d, const i
             AT_HIP(hipEventCreateWithFlags(&ctx->side_ev[0], hipEventDisableTiming));
             AT_HIP(hipEventCreateWithFlags(&ctx->side_ev[1], hipEventDisableTiming));
         }
-        int* pw = static_cast<int*>(at_ws(ctx, WS_LONG_PRED, ((size_t)k + 16) * 4, stream));
+        int* pw = static_cast<int*>(at_ws(ctx, WS_LONG_PRED, LongPred::bytes(k), stream));
         const int nblk = (int)((n + EARLY_ROWS - 1) / EARLY_ROWS);
         uint32_t* ew = static_cast<uint32_t*>(at_ws(ctx, WS_LONG_EARLY, ((size_t)2 * EARLY_MAX * nblk + EARLY_MAX + 1 + nn) * 4, stream));
         if (!pw || !ew) return AT_E_NOMEM;
         if (ctx->long_pred_k != k) {
-            AT_HIP(hipMemsetAsync(pw, 0, ((size_t)k + 16) * 4, stream));
+            AT_HIP(hipMemsetAsync(pw, 0, LongPred::bytes(k), stream));
             ctx->long_pred_k = k;
             ctx->long_gen = 0;
         }
+        const LongPred lp(pw);
         uint32_t* blockcnt = ew;
         uint32_t* blockbase = ew + (size_t)EARLY_MAX * nblk;
         uint32_t* eoff = blockbase + (size_t)EARLY_MAX * nblk;
@@ -893,24 +894,22 @@ int at_centroid_accum_f32(at_ctx* ctx, const float* x, int64_t n, int d, const i
         AT_HIP(hipEventRecord(ctx->side_ev[0], stream));          // ids (and the marks) are ready
         AT_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->side_ev[0], 0));
         hipStream_t ss = ctx->side_stream;
-        hipLaunchKernelGGL(early_count_kernel, dim3(nblk), dim3(WG), 0, ss, reinterpret_cast<const long*>(ids), (long)n, pw + 1, pw,
+        AT_LAUNCH(early_count_kernel, dim3(nblk), dim3(WG), 0, ss, reinterpret_cast<const long*>(ids), (long)n, lp.pred, lp.pred_n,
                            nblk, blockcnt);
-        hipLaunchKernelGGL(early_scan_kernel, dim3(1), dim3(1024), 0, ss, blockcnt, nblk, blockbase, eoff);
-        hipLaunchKernelGGL(early_write_kernel, dim3(nblk), dim3(WG), 0, ss, reinterpret_cast<const long*>(ids), (long)n, pw + 1, pw,
+        AT_LAUNCH(early_scan_kernel, dim3(1), dim3(1024), 0, ss, blockcnt, nblk, blockbase, eoff);
+        AT_LAUNCH(early_write_kernel, dim3(nblk), dim3(WG), 0, ss, reinterpret_cast<const long*>(ids), (long)n, lp.pred, lp.pred_n,
                            nblk, blockbase, eoff, lists, nullptr);
-        hipLaunchKernelGGL(centroid_accum_long_kernel, dim3(EARLY_MAX, d / 4), dim3(WG), 0, ss, x, d, lists, eoff, 2048u, sums,
-                           counts, k, 1, pw + 1, pw, reinterpret_cast<unsigned*>(pw + 16), gen, 0, 0x7fffffff);
-        AT_LAUNCH_CHECK();
+        AT_LAUNCH(centroid_accum_long_kernel, dim3(EARLY_MAX, d / 4), dim3(WG), 0, ss, x, d, lists, eoff, 2048u, sums,
+                           counts, k, 1, lp.pred, lp.pred_n, lp.done, gen, 0, 0x7fffffff);
         // the regular pass rebuilds the prediction: its counter starts from zero once the early pass has read it
-        AT_HIP(hipMemsetAsync(pw, 0, 4, ss));
+        AT_HIP(hipMemsetAsync(lp.pred_n, 0, 4, ss));
     }
 
     const uint32_t* order = vals_a;
     const uint32_t* sorted_keys = keys_a;
     if (n > 0) {
-        hipLaunchKernelGGL(make_keys_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, stream,
+        AT_LAUNCH(make_keys_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, stream,
                            reinterpret_cast<const long*>(ids), (long)n, k, keys_a, vals_a);
-        AT_LAUNCH_CHECK();
         unsigned bits = 1;
         while ((1u << bits) <= (unsigned)k) bits++;  // keys take values 0..k
         rocprim::double_buffer<uint32_t> kb(keys_a, keys_b);
@@ -923,9 +922,8 @@ int at_centroid_accum_f32(at_ctx* ctx, const float* x, int64_t n, int d, const i
         order = vb.current();
         sorted_keys = kb.current();
     }
-    hipLaunchKernelGGL(segment_offsets_kernel, dim3((k + 1 + WG - 1) / WG), dim3(WG), 0, stream,
+    AT_LAUNCH(segment_offsets_kernel, dim3((k + 1 + WG - 1) / WG), dim3(WG), 0, stream,
                        sorted_keys, (long)n, k, offsets);
-    AT_LAUNCH_CHECK();
 
     const bool al = at_aligned16(x);
     int vec = 1;
@@ -944,38 +942,37 @@ int at_centroid_accum_f32(at_ctx* ctx, const float* x, int64_t n, int d, const i
     if (have_long) {
         AT_HIP(hipEventRecord(ctx->side_ev[0], stream));          // sorted lists and offsets are ready
         AT_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->side_ev[0], 0));
-        // pred / pred_n / done live in WS_LONG_PRED: [0] n predicted, [1..8] their clusters, then k generation marks
-        int* pw = static_cast<int*>(at_ws(ctx, WS_LONG_PRED, ((size_t)k + 16) * 4, stream));
+        // pred / pred_n / done live in WS_LONG_PRED (struct LongPred)
+        int* pw = static_cast<int*>(at_ws(ctx, WS_LONG_PRED, LongPred::bytes(k), stream));
         if (!pw) return AT_E_NOMEM;
         if (ctx->long_pred_k != k) {   // fresh (or another table size): no predictions, no marks
-            AT_HIP(hipMemsetAsync(pw, 0, ((size_t)k + 16) * 4, stream));
+            AT_HIP(hipMemsetAsync(pw, 0, LongPred::bytes(k), stream));
             ctx->long_pred_k = k;
             ctx->long_gen = 0;
         }
         const unsigned gen = ++ctx->long_gen;
-        int* pred_n = pw;
-        int* pred = pw + 1;
-        unsigned* done = reinterpret_cast<unsigned*>(pw + 16);
+        const LongPred lp(pw);
+        int* pred_n = lp.pred_n;
+        int* pred = lp.pred;
+        unsigned* done = lp.done;
         int* late = static_cast<int*>(at_ws(ctx, WS_LONG_LATE, ((size_t)k + 1) * 4, stream));
         if (!late) return AT_E_NOMEM;
         AT_HIP(hipMemsetAsync(late, 0, 4, ctx->side_stream));
-        hipLaunchKernelGGL(long_detect_kernel, dim3((k + WG - 1) / WG), dim3(WG), 0, ctx->side_stream, offsets, k, long_list,
+        AT_LAUNCH(long_detect_kernel, dim3((k + WG - 1) / WG), dim3(WG), 0, ctx->side_stream, offsets, k, long_list,
                            done, gen, pred, pred_n, late);
-        hipLaunchKernelGGL(centroid_accum_long_kernel, dim3(32, d / 4), dim3(WG), 0, ctx->side_stream, x, d, order,
+        AT_LAUNCH(centroid_accum_long_kernel, dim3(32, d / 4), dim3(WG), 0, ctx->side_stream, x, d, order,
                            offsets, long_list, sums, counts, k, 0, late, nullptr, done, gen, 0, 0x7fffffff);
-        AT_LAUNCH_CHECK();
         AT_HIP(hipEventRecord(ctx->side_ev[1], ctx->side_stream));
     }
     if (vec == 4)
-        hipLaunchKernelGGL(centroid_accum_kernel<4>, grid, dim3(WG), 0, stream, x, d, order, offsets, k,
+        AT_LAUNCH(centroid_accum_kernel<4>, grid, dim3(WG), 0, stream, x, d, order, offsets, k,
                            slabs, long_list, sums, counts);
     else if (vec == 2)
-        hipLaunchKernelGGL(centroid_accum_kernel<2>, grid, dim3(WG), 0, stream, x, d, order, offsets, k,
+        AT_LAUNCH(centroid_accum_kernel<2>, grid, dim3(WG), 0, stream, x, d, order, offsets, k,
                            slabs, long_list, sums, counts);
     else
-        hipLaunchKernelGGL(centroid_accum_kernel<1>, grid, dim3(WG), 0, stream, x, d, order, offsets, k,
+        AT_LAUNCH(centroid_accum_kernel<1>, grid, dim3(WG), 0, stream, x, d, order, offsets, k,
                            slabs, long_list, sums, counts);
-    AT_LAUNCH_CHECK();
     if (order_out && n > 0)
         AT_HIP(hipMemcpyAsync(order_out, order, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream));
     if (sorted_ids_out && n > 0)
@@ -988,7 +985,6 @@ int at_centroid_accum_f32(at_ctx* ctx, const float* x, int64_t n, int d, const i
         if (ctx->defer_join) ctx->join_pending = 1;
         else AT_HIP(hipStreamWaitEvent(stream, ctx->side_ev[1], 0));
     }
-    AT_LAUNCH_CHECK();
     return AT_OK;
 }
 
@@ -1001,10 +997,9 @@ int at_centroid_finalize_f32(at_ctx* ctx, const float* sums_parts, int64_t sums_
     AT_REQUIRE(sums_parts && counts_parts && centroids && hassign, "at_centroid_finalize_f32: null pointer");
     AT_HIP(hipSetDevice(ctx->device));
     const long total = (long)k * d;
-    hipLaunchKernelGGL(centroid_finalize_kernel, dim3((unsigned)((total + WG - 1) / WG)), dim3(WG), 0,
+    AT_LAUNCH(centroid_finalize_kernel, dim3((unsigned)((total + WG - 1) / WG)), dim3(WG), 0,
                        stream, sums_parts, (long)sums_part_stride, counts_parts,
                        (long)counts_part_stride, n_parts, k, d, centroids, hassign);
-    AT_LAUNCH_CHECK();
     return AT_OK;
 }
 
@@ -1013,9 +1008,8 @@ int at_sum_parts_f32(at_ctx* ctx, const float* parts, int64_t part_stride, int n
     AT_REQUIRE(ctx && n_parts >= 1 && m >= 0 && (m == 0 || (parts && out)), "at_sum_parts_f32: bad arguments");
     if (m == 0) return AT_OK;
     AT_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((m + WG - 1) / WG)), dim3(WG), 0, stream, parts, (long)part_stride,
+    AT_LAUNCH(sum_parts_kernel, dim3((unsigned)((m + WG - 1) / WG)), dim3(WG), 0, stream, parts, (long)part_stride,
                        n_parts, (long)m, out);
-    AT_LAUNCH_CHECK();
     return AT_OK;
 }
 
@@ -1035,8 +1029,15 @@ int at_sum_f32(at_ctx* ctx, const float* v, int64_t n, double* out, void* stream
     unsigned* ticket = static_cast<unsigned*>(at_ws(ctx, WS_SUM_TICKET, 16, stream));
     if (!ticket) return AT_E_NOMEM;
     if (fresh) AT_HIP(hipMemsetAsync(ticket, 0, 16, stream));
-    hipLaunchKernelGGL(sum_kernel, dim3(blocks), dim3(WG), 0, stream, v, (long)n, partial, ticket, out);
-    AT_LAUNCH_CHECK();
+    // The partial buffer and the arrival counter are the context's: two calls on different streams must not overlap
+    // (the wrong "last workgroup", a mixed sum, a counter that is never put back).  A call on another stream than the
+    // previous one waits for it.
+    if (!ctx->sum_ev) AT_HIP(hipEventCreateWithFlags(&ctx->sum_ev, hipEventDisableTiming));
+    if (ctx->sum_used && ctx->sum_stream != stream) AT_HIP(hipStreamWaitEvent(stream, ctx->sum_ev, 0));
+    AT_LAUNCH(sum_kernel, dim3(blocks), dim3(WG), 0, stream, v, (long)n, partial, ticket, out);
+    AT_HIP(hipEventRecord(ctx->sum_ev, stream));
+    ctx->sum_stream = stream;
+    ctx->sum_used = 1;
     return AT_OK;
 }
 
@@ -1048,8 +1049,7 @@ int at_any_nonfinite_f32(at_ctx* ctx, const float* v, int64_t n, int32_t* flag, 
     if (n == 0) return AT_OK;
     int blocks = (int)((n + WG - 1) / WG);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(nonfinite_kernel, dim3(blocks), dim3(WG), 0, stream, v, (long)n, flag);
-    AT_LAUNCH_CHECK();
+    AT_LAUNCH(nonfinite_kernel, dim3(blocks), dim3(WG), 0, stream, v, (long)n, flag);
     return AT_OK;
 }
 
@@ -1063,17 +1063,9 @@ int at_token_histogram_i64(at_ctx* ctx, const int64_t* ids, int64_t n, int k, in
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     const size_t lds = k <= HIST_LDS_BINS ? sizeof(unsigned int) * (size_t)k : 0;
-    if (lds > 48 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            AT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&histogram_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, HIST_LDS_BINS * 4));
-            raised = true;
-        }
-    }
-    hipLaunchKernelGGL(histogram_kernel, dim3(blocks), dim3(WG), lds, stream, reinterpret_cast<const long*>(ids), (long)n, k,
+    { const int rcl_ = at_raise_lds(ctx, reinterpret_cast<const void*>(&histogram_kernel), lds); if (rcl_) return rcl_; }
+    AT_LAUNCH(histogram_kernel, dim3(blocks), dim3(WG), lds, stream, reinterpret_cast<const long*>(ids), (long)n, k,
                        reinterpret_cast<unsigned long long*>(counts));
-    AT_LAUNCH_CHECK();
     return AT_OK;
 }
 

@@ -88,15 +88,20 @@ extern "C" int at_minmax_scale_clips_f32(at_ctx* ctx, float* x, int64_t n_clips,
     if (n_clips == 0) return AT_OK;
     AT_REQUIRE(x, "at_minmax_scale_clips_f32: null pointer");
     AT_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(minmax_scale_kernel, dim3((unsigned)n_clips), dim3(1024), 0, stream, x, (long)clip_elems);
-    AT_LAUNCH_CHECK();
+    AT_LAUNCH(minmax_scale_kernel, dim3((unsigned)n_clips), dim3(1024), 0, stream, x, (long)clip_elems);
     return AT_OK;
 }
 
 int* at_row_flag(at_ctx* ctx, hipStream_t stream) {
     const bool fresh = ctx->ws[WS_ROW_FLAG] == nullptr;
     int* f = static_cast<int*>(at_ws(ctx, WS_ROW_FLAG, 16, stream));
-    if (f && fresh && hipMemsetAsync(f, 0, 16, stream) != hipSuccess) return nullptr;
+    if (f && fresh) {
+        const hipError_t e = AT_HIP_TOLERATE(hipMemsetAsync(f, 0, 16, stream));
+        if (e != hipSuccess) {
+            at_fail(AT_E_HIP, "at_row_flag: hipMemsetAsync failed: %s", hipGetErrorString(e));
+            return nullptr;
+        }
+    }
     return f;
 }
 
@@ -113,8 +118,7 @@ extern "C" int at_logmel_nonfinite_take(at_ctx* ctx, int32_t* flag_out, void* st
     AT_HIP(hipSetDevice(ctx->device));
     int* f = at_row_flag(ctx, stream);
     if (!f) return AT_E_NOMEM;
-    hipLaunchKernelGGL(row_flag_take_kernel, dim3(1), dim3(1), 0, stream, f, flag_out);
-    AT_LAUNCH_CHECK();
+    AT_LAUNCH(row_flag_take_kernel, dim3(1), dim3(1), 0, stream, f, flag_out);
     return AT_OK;
 }
 
@@ -134,15 +138,9 @@ int at_l2norm_rows_flagged(at_ctx* ctx, const float* x, int64_t n, int d, float*
     int R = 256;
     while (R > 1 && (size_t)R * (d + 2) * sizeof(float) > 68 * 1024) R >>= 1;
     const size_t lds = (size_t)R * (d + 2) * sizeof(float);
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        AT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2norm_rows_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_lds = lds;
-    }
+    { const int rcl_ = at_raise_lds(ctx, reinterpret_cast<const void*>(&l2norm_rows_kernel), lds); if (rcl_) return rcl_; }
     const long blocks = (n + R - 1) / R;
-    hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)blocks), dim3(WG), lds, stream, x, (long)n, d,
+    AT_LAUNCH(l2norm_rows_kernel, dim3((unsigned)blocks), dim3(WG), lds, stream, x, (long)n, d,
                        R, y, bad);
-    AT_LAUNCH_CHECK();
     return AT_OK;
 }

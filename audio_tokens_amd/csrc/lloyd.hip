@@ -258,17 +258,9 @@ int at_lloyd_stats_split_f32(at_ctx* ctx, int d, int k, int64_t n, float* hassig
     if (rc) return rc;
     const int p_lds = k <= 16384;
     const size_t lds = p_lds ? (size_t)k * sizeof(float) : 0;
-    if (lds > 32 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            AT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&split_clusters_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * (int)sizeof(float)));
-            raised = true;
-        }
-    }
-    hipLaunchKernelGGL(split_clusters_kernel, dim3(1), dim3(WG), lds, stream, d, k, (long)n, hassign, centroids, empties,
+    { const int rcl_ = at_raise_lds(ctx, reinterpret_cast<const void*>(&split_clusters_kernel), lds); if (rcl_) return rcl_; }
+    AT_LAUNCH(split_clusters_kernel, dim3(1), dim3(WG), lds, stream, d, k, (long)n, hassign, centroids, empties,
                        nsplit_out, raw, (long)raw_n, state_end, p_lds, obj_parts, (long)obj_part_stride, n_parts, stats);
-    AT_LAUNCH_CHECK();
     return AT_OK;
 }
 
@@ -279,9 +271,8 @@ int at_lloyd_stats_f64(at_ctx* ctx, const float* hassign, int k, const double* o
                "at_lloyd_stats_f64: obj_parts / stats must be 8-byte aligned");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     AT_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(lloyd_stats_kernel, dim3(1), dim3(WG), 0, stream, hassign, k, obj_parts, (long)obj_part_stride,
+    AT_LAUNCH(lloyd_stats_kernel, dim3(1), dim3(WG), 0, stream, hassign, k, obj_parts, (long)obj_part_stride,
                        n_parts, stats);
-    AT_LAUNCH_CHECK();
     return AT_OK;
 }
 

@@ -406,23 +406,16 @@ extern "C" int at_logmel_f32(at_ctx* ctx, const float* wave, int64_t n_clips, in
     }
     AT_REQUIRE(lds <= 160 * 1024, "at_logmel_f32: n_mels=%d needs %zu bytes of LDS", n_mels, lds);
     const bool pf = ((p.fpb - 1) * hop + NFFT + 3) / 4 <= PREFETCH_REGS * WG;   // the block's samples fit the prefetch registers
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        AT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&logmel_kernel<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        AT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&logmel_kernel<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_lds = lds;
-    }
+    { const int rcl_ = at_raise_lds(ctx, reinterpret_cast<const void*>(&logmel_kernel<true>), lds); if (rcl_) return rcl_; }
+    { const int rcl_ = at_raise_lds(ctx, reinterpret_cast<const void*>(&logmel_kernel<false>), lds); if (rcl_) return rcl_; }
     p.blocks_per_clip = (int)((T + p.fpb - 1) / p.fpb);
     p.n_blocks = (long)p.blocks_per_clip * n_clips;
     // persistent workgroups: two per CU (what the LDS footprint allows), each walking a strided share
     // of the blocks with its window / twiddle tables in registers
     long grid = 2L * ctx->n_cus;
     if (grid > p.n_blocks) grid = p.n_blocks;
-    if (pf) hipLaunchKernelGGL(logmel_kernel<true>, dim3((unsigned)grid), dim3(WG), lds, stream, p);
-    else hipLaunchKernelGGL(logmel_kernel<false>, dim3((unsigned)grid), dim3(WG), lds, stream, p);
-    AT_LAUNCH_CHECK();
+    if (pf) AT_LAUNCH(logmel_kernel<true>, dim3((unsigned)grid), dim3(WG), lds, stream, p);
+    else AT_LAUNCH(logmel_kernel<false>, dim3((unsigned)grid), dim3(WG), lds, stream, p);
     if (fuse_l2norm && !fuse_here) return at_l2norm_rows_flagged(ctx, out, n_clips * T, n_mels, out, p.bad, stream);
     return AT_OK;
 }

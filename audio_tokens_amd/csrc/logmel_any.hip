@@ -189,15 +189,10 @@ int at_logmel_any(at_ctx* ctx, const float* wave, int64_t n_clips, int64_t L, in
     p.fb_wts = reinterpret_cast<const float*>(ints + nint);
     p.out = out; p.frame_major = frame_major;
     const size_t lds = (size_t)(WG / 64) * (N + M + 4) * sizeof(float);
-    static size_t attr_lds = 0;
-    if (lds > 48 * 1024 && lds > attr_lds) {
-        AT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&logmel_any_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_lds = lds;
-    }
+    { const int rcl_ = at_raise_lds(ctx, reinterpret_cast<const void*>(&logmel_any_kernel), lds); if (rcl_) return rcl_; }
     long grid = 8L * ctx->n_cus;
     const long need = (p.n_frames + WG / 64 - 1) / (WG / 64);
     if (grid > need) grid = need;
-    hipLaunchKernelGGL(logmel_any_kernel, dim3((unsigned)grid), dim3(WG), lds, stream, p);
-    AT_LAUNCH_CHECK();
+    AT_LAUNCH(logmel_any_kernel, dim3((unsigned)grid), dim3(WG), lds, stream, p);
     return AT_OK;
 }

@@ -324,17 +324,15 @@ int at_prune_prepass(at_ctx* ctx, const float* x, int64_t n, int d, const float*
                      float* bd_out, uint32_t* mask, int ngw, int mode, hipStream_t stream) {
     if (mode == 1) {  // hint_sorted holds group ids: each tile needs just those groups (+ neighbours)
         const long waves1 = (n + 63) / 64;
-        hipLaunchKernelGGL(group_only_mask_kernel, dim3((unsigned)((waves1 + WG / 64 - 1) / (WG / 64))), dim3(WG), 0,
+        AT_LAUNCH(group_only_mask_kernel, dim3((unsigned)((waves1 + WG / 64 - 1) / (WG / 64))), dim3(WG), 0,
                            stream, (long)n, hint_sorted, ng, reinterpret_cast<const uint32_t*>(dmin), bd_out, mask,
                            ngw);
-        AT_LAUNCH_CHECK();
         return AT_OK;
     }
     unsigned* cnmax = static_cast<unsigned*>(at_ws(ctx, WS_REDUCE, 1024 * sizeof(double), stream));
     if (!cnmax) return AT_E_NOMEM;
     AT_HIP(hipMemsetAsync(cnmax, 0, sizeof(unsigned), stream));
-    hipLaunchKernelGGL(max_sqnorm_kernel, dim3((k + WG - 1) / WG), dim3(WG), 0, stream, c, k, d, cnmax);
-    AT_LAUNCH_CHECK();
+    AT_LAUNCH(max_sqnorm_kernel, dim3((k + WG - 1) / WG), dim3(WG), 0, stream, c, k, d, cnmax);
     const long waves = (n + 63) / 64;
     const dim3 grid((unsigned)((waves + WG / 64 - 1) / (WG / 64)));
     const bool fresh = ctx->ws[WS_PRUNE_STATS] == nullptr;
@@ -342,12 +340,11 @@ int at_prune_prepass(at_ctx* ctx, const float* x, int64_t n, int d, const float*
     if (!stats) return AT_E_NOMEM;
     if (fresh) AT_HIP(hipMemsetAsync(stats, 0, 4096, stream));
     if (d == 64)
-        hipLaunchKernelGGL(prune_mask_kernel<64>, grid, dim3(WG), 0, stream, x, (long)n, c, k, order, hint_sorted,
+        AT_LAUNCH(prune_mask_kernel<64>, grid, dim3(WG), 0, stream, x, (long)n, c, k, order, hint_sorted,
                            dmin, ng, cnmax, bd_out, mask, ngw, stats);
     else
-        hipLaunchKernelGGL(prune_mask_kernel<128>, grid, dim3(WG), 0, stream, x, (long)n, c, k, order, hint_sorted,
+        AT_LAUNCH(prune_mask_kernel<128>, grid, dim3(WG), 0, stream, x, (long)n, c, k, order, hint_sorted,
                            dmin, ng, cnmax, bd_out, mask, ngw, stats);
-    AT_LAUNCH_CHECK();
     return AT_OK;
 }
 
@@ -364,10 +361,9 @@ int at_group_min_dist_f32(at_ctx* ctx, const float* c, int k, int d, const int32
     ctx->img16_c = nullptr;  // (no fp16 image is left behind by this form)
     const dim3 grid(ng, (k + WG - 1) / WG);
     if (d == 64)
-        hipLaunchKernelGGL(group_min_dist_kernel<64>, grid, dim3(WG), 0, stream, c, k, cperm, ng, dmin);
+        AT_LAUNCH(group_min_dist_kernel<64>, grid, dim3(WG), 0, stream, c, k, cperm, ng, dmin);
     else
-        hipLaunchKernelGGL(group_min_dist_kernel<128>, grid, dim3(WG), 0, stream, c, k, cperm, ng, dmin);
-    AT_LAUNCH_CHECK();
+        AT_LAUNCH(group_min_dist_kernel<128>, grid, dim3(WG), 0, stream, c, k, cperm, ng, dmin);
     return AT_OK;
 }
 
@@ -392,8 +388,7 @@ int at_group_means_f32(at_ctx* ctx, const float* c, int k, int d, const int32_t*
     hipStream_t stream = (hipStream_t)stream_;
     AT_REQUIRE(ctx && c && cperm && means && k > 0 && d > 0 && ng > 0, "at_group_means_f32: bad arguments");
     AT_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(group_means_kernel, dim3(ng), dim3(WG), 0, stream, c, d, cperm, means);
-    AT_LAUNCH_CHECK();
+    AT_LAUNCH(group_means_kernel, dim3(ng), dim3(WG), 0, stream, c, d, cperm, means);
     return AT_OK;
 }
 
@@ -402,8 +397,7 @@ int at_group_neighbours_f32(at_ctx* ctx, const float* means, int ng, int d, int 
     AT_REQUIRE(ctx && means && gnbr, "at_group_neighbours_f32: null pointer");
     AT_REQUIRE(ng > 0 && ng <= 512 && d > 0 && d <= 128 && nnb > 0, "at_group_neighbours_f32: needs ng <= 512, d <= 128, nnb > 0");
     AT_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(group_neighbours_kernel, dim3(ng), dim3(256), 0, stream, means, ng, d, nnb, gnbr);
-    AT_LAUNCH_CHECK();
+    AT_LAUNCH(group_neighbours_kernel, dim3(ng), dim3(256), 0, stream, means, ng, d, nnb, gnbr);
     return AT_OK;
 }
 
@@ -427,9 +421,8 @@ int at_visit_order_f32(at_ctx* ctx, const int64_t* ids, const float* dis, int64_
     if (dbits < 0) dbits = 0;
     if (dbits > 12) dbits = 12;
     if ((int)cbits + dbits > 32) dbits = 32 - (int)cbits;
-    hipLaunchKernelGGL(visit_keys_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, stream,
+    AT_LAUNCH(visit_keys_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, stream,
                        reinterpret_cast<const long*>(ids), dis, (long)n, k, keys_a, vals_a, dbits);
-    AT_LAUNCH_CHECK();
     const unsigned bits = cbits + (unsigned)dbits;
     rocprim::double_buffer<uint32_t> kb(keys_a, keys_b);
     rocprim::double_buffer<uint32_t> vb(vals_a, vals_b);
@@ -438,9 +431,8 @@ int at_visit_order_f32(at_ctx* ctx, const int64_t* ids, const float* dis, int64_
     void* tmp = at_ws(ctx, WS_VISIT_TMP, tmp_bytes, stream);
     if (!tmp) return AT_E_NOMEM;
     AT_HIP(rocprim::radix_sort_pairs<at_radix_config>(tmp, tmp_bytes, kb, vb, (size_t)n, 0, bits, stream));
-    hipLaunchKernelGGL(key_to_hint_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, stream, kb.current(),
+    AT_LAUNCH(key_to_hint_kernel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, stream, kb.current(),
                        vb.current(), (long)n, hint_sorted_out, order_out, dbits);
-    AT_LAUNCH_CHECK();
     return AT_OK;
 }
 

@@ -111,8 +111,7 @@ int at_mt_cached_draws(at_ctx* ctx, uint32_t seed, hipStream_t stream, const uin
     if (!ctx->mt_ready) AT_HIP(hipEventCreateWithFlags(&ctx->mt_ready, hipEventDisableTiming));
     if (!ctx->mt_have || ctx->mt_seed != seed) {
         if (ctx->mt_have) AT_HIP(hipDeviceSynchronize());   // another seed's consumers may still be reading
-        mt19937_kernel<<<1, 256, 0, stream>>>(seed, n_draws, buf, buf + n_draws);
-        AT_LAUNCH_CHECK();
+        AT_LAUNCH(mt19937_kernel, dim3(1), dim3(256), 0, stream, seed, n_draws, buf, buf + n_draws);
         AT_HIP(hipEventRecord(ctx->mt_ready, stream));
         ctx->mt_have = 1;
         ctx->mt_seed = seed;
@@ -158,12 +157,10 @@ extern "C" int at_rand_perm_prefix_device(at_ctx* ctx, int64_t n, int64_t seed, 
     const unsigned tb = 256;
     if (steps > 0) {
         if (raw_own) {
-            mt19937_kernel<<<1, 256, 0, stream>>>((uint32_t)seed, steps, raw_own, nullptr);
-            AT_LAUNCH_CHECK();
+            AT_LAUNCH(mt19937_kernel, dim3(1), dim3(256), 0, stream, (uint32_t)seed, steps, raw_own, nullptr);
         }
         const unsigned gs = (unsigned)((steps + tb - 1) / tb);
-        perm_keys_kernel<<<gs, tb, 0, stream>>>(raw, steps, n, ka, va);
-        AT_LAUNCH_CHECK();
+        AT_LAUNCH(perm_keys_kernel, dim3(gs), dim3(tb), 0, stream, raw, steps, n, ka, va);
         int bits = 1;
         while (bits < 32 && (uint64_t(1) << bits) <= (uint64_t)n) bits++;
         rocprim::double_buffer<uint32_t> kbuf(ka, kb);
@@ -173,10 +170,8 @@ extern "C" int at_rand_perm_prefix_device(at_ctx* ctx, int64_t n, int64_t seed, 
         void* tmp = at_ws(ctx, WS_PERM_TMP, tmp_bytes, stream);
         if (!tmp) return AT_E_NOMEM;
         AT_HIP(rocprim::radix_sort_pairs<perm_radix_config>(tmp, tmp_bytes, kbuf, vbuf, (size_t)steps, 0, bits, stream));
-        perm_links_kernel<<<gs, tb, 0, stream>>>(kbuf.current(), vbuf.current(), steps, n, m, prev, last);
-        AT_LAUNCH_CHECK();
+        AT_LAUNCH(perm_links_kernel, dim3(gs), dim3(tb), 0, stream, kbuf.current(), vbuf.current(), steps, n, m, prev, last);
     }
-    perm_resolve_kernel<<<(unsigned)((m + tb - 1) / tb), tb, 0, stream>>>(raw, prev, last, steps, n, m, prefix);
-    AT_LAUNCH_CHECK();
+    AT_LAUNCH(perm_resolve_kernel, dim3((unsigned)((m + tb - 1) / tb)), dim3(tb), 0, stream, raw, prev, last, steps, n, m, prefix);
     return AT_OK;
 }

@@ -179,15 +179,14 @@ int at_resample_f32(at_ctx* ctx, const float* wave, int64_t n_clips, int64_t L, 
         const long cap = ((n_i + RI - 1) / RI) * RI;  // no point in tiles longer than the clip
         if (TI > cap) TI = cap;
         const size_t lds = sizeof(float) * (size_t)((TI - 1) * orig + K);
-        hipLaunchKernelGGL(resample_tiled_kernel<RI>, dim3((unsigned)((n_i + TI - 1) / TI), (unsigned)n_clips),
+        AT_LAUNCH(resample_tiled_kernel<RI>, dim3((unsigned)((n_i + TI - 1) / TI), (unsigned)n_clips),
                            dim3(WG), lds, stream, wave, (long)L, (long)wave_stride, taps, orig, nw, K, width, (int)TI,
                            nw < 32 ? 1 : 0, (long)out_len, (long)out_stride, out);
     } else {
-        hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((out_len + WG - 1) / WG), (unsigned)n_clips), dim3(WG),
+        AT_LAUNCH(resample_kernel, dim3((unsigned)((out_len + WG - 1) / WG), (unsigned)n_clips), dim3(WG),
                            0, stream, wave, (long)n_clips, (long)L, (long)wave_stride, taps, orig, nw, K, width,
                            (long)out_len, (long)out_stride, out);
     }
-    AT_LAUNCH_CHECK();
     return AT_OK;
 }
 

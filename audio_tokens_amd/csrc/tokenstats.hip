@@ -110,8 +110,7 @@ extern "C" int at_token_stats_f64(at_ctx* ctx, const int64_t* counts, int k, int
     AT_HIP(hipSetDevice(ctx->device));
     int32_t* iota = static_cast<int32_t*>(at_ws(ctx, WS_TSTAT_IOTA, (size_t)k * 4, stream));
     if (!iota) return AT_E_NOMEM;
-    hipLaunchKernelGGL(iota_kernel, dim3((k + WG - 1) / WG), dim3(WG), 0, stream, iota, k);
-    AT_LAUNCH_CHECK();
+    AT_LAUNCH(iota_kernel, dim3((k + WG - 1) / WG), dim3(WG), 0, stream, iota, k);
     const unsigned long long* kin = reinterpret_cast<const unsigned long long*>(counts);
     unsigned long long* kout = reinterpret_cast<unsigned long long*>(sorted_counts);
     size_t tmp_bytes = 0;
@@ -119,7 +118,6 @@ extern "C" int at_token_stats_f64(at_ctx* ctx, const int64_t* counts, int k, int
     void* tmp = at_ws(ctx, WS_TSTAT_TMP, tmp_bytes, stream);
     if (!tmp) return AT_E_NOMEM;
     AT_HIP(rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, kin, kout, iota, sorted_tokens, (size_t)k, 0, 64, stream));
-    hipLaunchKernelGGL(token_stats_kernel, dim3(1), dim3(WG), 0, stream, kout, k, stats);
-    AT_LAUNCH_CHECK();
+    AT_LAUNCH(token_stats_kernel, dim3(1), dim3(WG), 0, stream, kout, k, stats);
     return AT_OK;
 }

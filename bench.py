@@ -147,6 +147,7 @@ def main():
     from audio_tokens_amd.synth import synth_clips
 
     be = default_backend(device)
+    be.debug_set("filter_timing", 1)   # the library brackets the stage-1 kernel of its exact calls with HIP events (roofline)
     sr, hop, n_fft = 22050, 128, 512
     L = int(round(args.clip_seconds * sr))
     T = be.num_frames(L, hop)

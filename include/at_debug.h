@@ -8,8 +8,18 @@
  *                                 from the environment again; names:
  *                                   assign_variant filter_fused filter_sync prune_kernel prune_nb filter_screen
  *                                   filter_nb filter_wps2 dmin_kernel resample_simple accum_buckets filter_stats visit_bits
+ *                                   filter_timing strict_errors
  *                                 (filter_stats = 1 makes the fp16-split sweeps count for the two calls below: one record
  *                                 per workgroup and a small reduction kernel behind every sweep; off by default)
+ *                                 filter_timing = 1 brackets the stage-1 kernel of every exact call with two timing events
+ *                                 (what at_filter_stats' sweep_ms sums; bench.py turns it on, the product leaves it off);
+ *                                 strict_errors (process-wide, also AT_STRICT_ERRORS): a HIP error found pending in the
+ *                                 calling thread in front of one of the library's launches fails the call ("stale error
+ *                                 from an earlier call") instead of being consumed and counted
+ *   at_diag_errors                what the library met and did not treat as its own failure: errors pending in front of a
+ *                                 launch (somebody's earlier call failed and nobody consumed the error) and failures it
+ *                                 tolerates by design; counts, last codes and source positions.  No device work.
+ *   at_debug_leave_error_pending  test hook: makes a HIP call fail without consuming its error, as a swallowed return code does
  *   at_prune_stats                running totals over the context's exact pruned sweeps: 32x32 accumulators computed /
  *                                 accumulators of the dense sweep.  Synchronises the device; reset != 0 clears them.
  *   at_filter_stats               fp16-split filter: rows swept / rows handed to the fp32 redo, the summed HIP-event
@@ -29,6 +39,9 @@ extern "C" {
 
 int at_debug_set(at_ctx* ctx, const char* name, int value);
 int at_debug_get(const at_ctx* ctx, const char* name, int* value);
+int at_diag_errors(int64_t* stale_seen, int* stale_last_code, int64_t* tolerated, int* tolerated_last_code, char* where,
+                   int where_bytes, int reset);
+int at_debug_leave_error_pending(void);
 
 int at_prune_stats(at_ctx* ctx, int64_t* needed_host, int64_t* total_host, int reset);
 int at_filter_stats(at_ctx* ctx, int64_t* rows, int64_t* listed, double* sweep_ms, int64_t* sweeps,

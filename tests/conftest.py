@@ -9,6 +9,9 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# the test-suite runs the library in its strict mode: a HIP error that is pending in the calling thread when the library
+# is about to launch a kernel -- somebody swallowed a failing call -- fails the test (include/at_debug.h: strict_errors)
+os.environ.setdefault("AT_STRICT_ERRORS", "1")
 
 
 def pytest_configure(config):
@@ -48,7 +51,7 @@ def be():
 
 _NATIVE_DEFAULTS = {"assign_variant": 0, "filter_fused": 1, "filter_sync": 0, "prune_kernel": 1, "prune_nb": 0,
                     "filter_screen": 1, "filter_nb": 0, "filter_wps2": 0, "dmin_kernel": 1, "resample_simple": 0,
-                    "accum_buckets": 1, "filter_stats": 0, "visit_bits": 8}
+                    "accum_buckets": 1, "filter_stats": 0, "visit_bits": 8, "filter_timing": 0}
 
 
 @pytest.fixture()

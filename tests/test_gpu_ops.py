@@ -345,6 +345,35 @@ def test_centroid_accum_long_lists_both_paths(be, switches, buckets, n, d, k, n_
     assert (buckets == 0) or (n > 64 * k) or (d % 4) or int((counts > 2048).sum()) == n_long
 
 
+@pytest.mark.parametrize("d", [64, 128])
+def test_centroid_accum_sort_path_with_more_long_clusters_than_early_slots(be, switches, d):
+    """WS_LONG_PRED keeps [count | EARLY_MAX predicted ids | k generation marks].  With the marks laid over the last id
+    (round 2) a call with >= 16 long clusters wrote a cluster id into done[0] while cluster 0's thread read it: a long
+    cluster 0 could be left un-summed.  Sort path, 20 long clusters INCLUDING cluster 0, four calls in a row (the second
+    one onward sums the predicted clusters early), every call against the sequential sum, bit for bit."""
+    switches(accum_buckets=0)
+    n, k, n_long = 360000, 3000, 20
+    rng = np.random.default_rng(d)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    xt = be._f32(x)
+    heavy = np.concatenate([[0], 1 + rng.choice(k - 1, n_long - 1, replace=False)])
+    for call in range(4):
+        ids = rng.integers(0, k, n)
+        pick = rng.random(n) < 0.75
+        ids[pick] = heavy[rng.integers(0, n_long, int(pick.sum()))]
+        if call == 2:                                   # the long set changes between calls: predictions partly wrong
+            ids[ids == heavy[3]] = heavy[4]
+        idt = torch.from_numpy(ids).to(be.device)
+        part = be.centroid_accum(xt, idt, k)
+        sums = np.zeros((k, d), np.float32)
+        np.add.at(sums, ids, x)
+        counts = np.bincount(ids, minlength=k).astype(np.float32)
+        p = part.cpu().numpy()
+        assert int((counts > 2048).sum()) >= 17 and counts[0] > 2048
+        assert np.array_equal(p[k * d: k * d + k], counts), call
+        assert np.array_equal(bits(p[: k * d].reshape(k, d)), bits(sums)), call
+
+
 def test_sum_and_nonfinite(be):
     rng = np.random.default_rng(1)
     v = rng.random(1_000_003).astype(np.float32)

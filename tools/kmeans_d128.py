@@ -6,6 +6,7 @@ from audio_tokens_amd.backend import default_backend
 from audio_tokens_amd.ops import Kmeans
 from audio_tokens_amd.synth import synth_clips
 be = default_backend()
+be.debug_set("filter_timing", 1)
 wave = synth_clips(1300, device="cuda")
 x = be.logmel(wave, 22050, 512, 128, 128, frame_major=True, l2norm=True)[:2097152].contiguous()
 del wave

@@ -8,6 +8,7 @@ from audio_tokens_amd.backend import default_backend
 from audio_tokens_amd.synth import synth_clips
 
 be = default_backend()
+be.debug_set("filter_timing", 1)
 k = 8192
 wave = synth_clips(int(os.environ.get("CLIPS", "6000")), L=220500, seed=4242, device=be.device)
 fr = be.logmel(wave, 22050, 512, 128, 64, frame_major=True, l2norm=True)
