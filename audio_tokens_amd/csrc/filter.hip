@@ -35,21 +35,12 @@
 
 #include <rocprim/rocprim.hpp>
 
-#include "at_internal.h"
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "filter_common.h"
 
 namespace {
+using namespace atf;
 
 constexpr int WG = 256;
-constexpr unsigned NONE = 0xffffffffu;
-constexpr float RANGE_SQ = 1073741824.0f;  // 2^30: |v| < 2^15 for every component
-
-__host__ __device__ constexpr size_t group_bytes(int d) { return (size_t)32 * d * 4 + 1024; }
-__host__ __device__ constexpr size_t misc_off(int d) { return (size_t)(d / 16) * 1024; }   // |c|^2, +128: indices
-__host__ __device__ constexpr size_t lo_off(int d) { return (size_t)(d / 16) * 1024 + 1024; }
 
 // Image of group g, hot part first: hi fragments [s = feature/16][lane][8 halves] (lane = 32 * ((f % 16)
 // / 8) + slot, exactly the A operand of v_mfma_f32_32x32x16_f16, 1 KiB per fragment), then 256 bytes of
@@ -103,33 +94,6 @@ __global__ void __launch_bounds__(WG) prep_centroids_f16_kernel(const float* __r
 // distance comes within rho of that row's runner-up cannot change anybody's (best, runner-up)
 // pair, so its two lo products (8 of the 12 MFMAs) are skipped and the lo fragments of the group
 // are fetched only when some tile asks for them.
-__device__ __forceinline__ float min16(const float (&p)[16]) {
-    const float a = __builtin_fminf(__builtin_fminf(p[0], p[1]), __builtin_fminf(p[2], p[3]));
-    const float b = __builtin_fminf(__builtin_fminf(p[4], p[5]), __builtin_fminf(p[6], p[7]));
-    const float c = __builtin_fminf(__builtin_fminf(p[8], p[9]), __builtin_fminf(p[10], p[11]));
-    const float d = __builtin_fminf(__builtin_fminf(p[12], p[13]), __builtin_fminf(p[14], p[15]));
-    return __builtin_fminf(__builtin_fminf(a, b), __builtin_fminf(c, d));
-}
-
-// What the fused pre-pass needs (FUSED instantiation): the guesses in visiting order, the raw
-// centroids, the centroid-to-group bounds, and where to leave the exact guess distances / statistics.
-struct FusedPrepass {
-    const uint32_t* hint_sorted;
-    const float* C;
-    const float* dmin;
-    float* bd_out;
-    float* dist_out;   // optional: the guess distance where the winner is the guess, DIST_TODO elsewhere
-    unsigned long long* stats;   // (unused by the sweep since round 2: see blk_stats)
-    int k;
-    // guess generator over rows in their own order (frames of clips): nearest group mean first, then the
-    // groups its neighbour table names -- both inside one launch
-    const unsigned char* means_img;
-    const uint32_t* gnbr;
-    int ngm;
-};
-constexpr unsigned DIST_TODO = 0x7fc0deadu;  // a NaN no computed distance can be
-constexpr unsigned AMB_SUBLISTS = 64;      // the rows a sweep lists for the redo are appended to 64 sub-lists
-
 template <int D, int NB, bool GUESS, bool FUSED, int WPS = 2>
 __global__ void __launch_bounds__(64, WPS)
 assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char* __restrict__ img, int ng,
@@ -278,16 +242,6 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
         i1[b] = NONE;
         i2[b] = NONE;
     }
-    // insert (P, idx) into a sorted triple (v1 <= v2 <= v3) with the slots of the first two
-    auto insert3 = [](float P, unsigned idx, float& v1, float& v2, float& v3, unsigned& j1, unsigned& j2) {
-        const bool lt1 = P < v1, lt2 = P < v2;
-        const float n3 = __builtin_amdgcn_fmed3f(v2, v3, __builtin_fmaxf(v1, P));
-        j2 = lt1 ? j1 : (lt2 ? idx : j2);
-        v2 = __builtin_amdgcn_fmed3f(v1, v2, P);
-        j1 = lt1 ? idx : j1;
-        v1 = __builtin_fminf(v1, P);
-        v3 = n3;
-    };
 
     // needed groups of this wave, compacted: entry = group | (tile bits << 9)
     int cnt = 0;
@@ -1221,6 +1175,27 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
     // exact calls (collect) and guess generators are separate instantiations: the guess path's code
     // would otherwise cost the exact sweep registers it does not have
     const dim3 grid64((unsigned)((n + 63) / 64));
+    // d = 64 exact fused sweeps: four waves around one fragment stream (filter_wg.hip); switch filter_wg = 0 keeps the
+    // one-wave-per-workgroup kernels below (A/B aid, and still the form of d = 128 and of the guess generators)
+    const bool use_wg = fused && d == 64 && ctx->dbg.filter_wg != 0 && nbv != 4;
+    if (use_wg) {
+        const int tpw = nbv ? (nbv == 1 ? 1 : 2) : (n <= (int64_t)1 << 19 ? 1 : 2);
+        const unsigned n_wgw = (unsigned)((n + 128 * tpw - 1) / (128 * tpw)) * 4u;   // one record per wave
+        if (ctx->dbg.filter_stats) {
+            blk_stats = static_cast<uint4*>(at_ws(ctx, WS_FILTER_BLKSTATS, (size_t)n_wgw * sizeof(uint4), stream));
+            if (!blk_stats) return AT_E_NOMEM;
+        }
+        const int rcw = at_filter_sweep_wg(ctx, x, n, d, img, ng, order, misc, ta, tb, ra, rb, screen, ids, amb_list, amb_aux,
+                                           approx_out, fp, blk_stats, amb_cap, tpw, stream);
+        if (rcw) return rcw;
+        if (timed) {
+            AT_HIP(hipEventRecord(tslot.ev[1], stream));
+            tslot.timed = 1;
+        }
+        if (blk_stats)
+            AT_LAUNCH(filter_stats_reduce_kernel, dim3(1), dim3(1024), 0, stream, blk_stats, n_wgw, fp.stats, misc);
+        return AT_OK;
+    }
     if (d == 128) {  // two tiles per wave: the fragment sets of d = 128 leave no registers for four
         if (fused) AT_FILTER_LAUNCH(128, 2, false, true, grid64);
         else if (collect) AT_FILTER_LAUNCH(128, 2, false, false, grid64);

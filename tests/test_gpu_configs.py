@@ -85,17 +85,18 @@ def test_config1_two_batches_against_the_oracle(be, oracle):
     assert [len(s) for s in res.kmeans_stats] == [20, 20]
 
 
-@pytest.mark.parametrize("k,n1,n2", [(2048, 60000, 40000), (8192, 70000, 30000)])
+@pytest.mark.parametrize("k,n1,n2", [(2048, 60000, 40000), (8192, 70000, 30000), (16384, 70000, 30000)])
 def test_kmeans_d128_pruned_path_matches_oracle(be, oracle, switches, k, n1, n2):
-    """configs[2] / configs[4] feature width: assign_f16filter_kernel<128,...>, its fused pre-pass and the d=128
-    redo paths inside a full train(), cold start then warm start, filter on and off, against the oracle."""
+    """configs[2] / configs[4] feature width and table sizes (k = 16 384 is configs[4]'s vocabulary: 512 groups, the
+    bucket path's and split_clusters' largest LDS tables): assign_f16filter_kernel<128,...>, its fused pre-pass and the
+    d=128 redo paths inside a full train(), cold start then warm start, filter on and off, against the oracle."""
     from audio_tokens_amd.ops import Kmeans
     rng = np.random.default_rng(k)
     cen = rng.standard_normal((k, 128))
     x = (cen[rng.integers(0, k, n1 + n2)] + 0.5 * rng.standard_normal((n1 + n2, 128))).astype(np.float32)
     x = oracle.l2norm_rows(x)
     x[:200] = x[200:400]                                    # duplicates
-    niter = 6
+    niter = 6 if k < 16384 else 4
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         r1 = oracle.kmeans_train(x[:n1], k, niter=niter)
@@ -146,21 +147,29 @@ def test_full_size_d128_lloyd_shape_properties(be, n, k):
     assert int(torch.bincount(ids_d, minlength=k).sum()) == n
 
 
-@pytest.mark.parametrize("d,n_clips", [(64, 1218), (128, 1218)])
-def test_full_size_20_iterations_accelerated_equals_dense(be, d, n_clips):
+@pytest.mark.parametrize("d,k,niter,n_clips", [(64, 8192, 20, 1218), (128, 8192, 20, 1218), (128, 16384, 5, 2440)])
+def test_full_size_20_iterations_accelerated_equals_dense(be, d, k, niter, n_clips):
     """configs[3] (d=64) and configs[2] (d=128) Lloyd shape, all 20 iterations of one FAISS-recipe training on
     2 097 152 rows x 8192 clusters: pruning + fp16 filter + guess generators against plain dense fp32 sweeps.
-    Centroids, repairs and objectives must be bit-equal, and so must a warm-started second training."""
+    Centroids, repairs and objectives must be bit-equal, and so must a warm-started second training.
+    configs[4]'s shape (d=128, 16 384 clusters): the training frames of 2 440 clips (4 204 120 rows) are cut to the
+    256 k = 4 194 304-row subsample by the device permutation inside train(), five iterations cold and five warm."""
     from audio_tokens_amd.ops import Kmeans
     from audio_tokens_amd.synth import synth_clips
-    wave = synth_clips(n_clips, L=220500, seed=99, device=be.device)
-    x = be.logmel(wave, 22050, 512, 128, d, frame_major=True, l2norm=True)
-    assert x.shape[0] >= 2097152
-    x2 = x[:1500000]
-    x = x[-2097152:].contiguous()
+    rows = 256 * k
+    x = torch.empty((n_clips * 1723, d), dtype=torch.float32, device=be.device)
+    for c0 in range(0, n_clips, 610):
+        c1 = min(n_clips, c0 + 610)
+        wave = synth_clips(c1 - c0, L=220500, seed=99, first_clip=c0, device=be.device)
+        be.logmel(wave, 22050, 512, 128, d, frame_major=True, l2norm=True, out=x[c0 * 1723:c1 * 1723])
+        del wave
+    assert x.shape[0] >= rows
+    x2 = x[:rows * 3 // 4]
+    # (k = 8192: exactly 256 k rows, no subsampling; k = 16 384: a few thousand rows more, so train() subsamples)
+    x = x[-rows:].contiguous() if k == 8192 else x
     runs = {}
     for prune in (True, False):
-        km = Kmeans(d, 8192, niter=20, backend=be)
+        km = Kmeans(d, k, niter=niter, backend=be)
         km.prune = prune
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")

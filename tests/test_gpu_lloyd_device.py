@@ -14,7 +14,7 @@ def bits(a):
 
 @pytest.mark.parametrize("n,m", [(1, 1), (2, 1), (2, 2), (3, 3), (7, 7), (100, 100), (100, 99), (100, 1), (625, 625),
                                  (1000, 37), (5000, 4999), (70000, 70000), (200000, 65536), (1000003, 131072),
-                                 (4307500, 2097152), (17230000, 2097152)])
+                                 (4307500, 2097152), (17230000, 2097152), (17230000, 4194304)])
 def test_rand_perm_device_equals_host(be, n, m):
     """at_rand_perm_prefix_device == first m entries of faiss' rand_perm(n, seed): full permutations (every
     position touched many times), self swaps, prefixes, the benchmark's sizes; two seeds."""

@@ -169,6 +169,28 @@ def test_streaming_pipeline_equals_resident(be, clips, seconds, k, batch, chunk,
     assert torch.equal(got.tokens_val, ref.tokens_val.cpu())
 
 
+def test_streaming_at_size_two_batches_pinned(be):
+    """configs[4]'s mode at a size where the staging matters: 2 200 + 200 ten-second clips in PINNED host memory
+    (2.1 GB), k-means batches of 1 000 files (three trainings, two of them warm-started), 500-clip chunks through the
+    two staging slots -- centroids and all 4.1 M tokens equal to run() on the resident waveforms, bit for bit."""
+    from audio_tokens_amd.pipeline import DevicePipeline
+    from audio_tokens_amd.synth import synth_clips
+    n_tr, n_va = 2200, 200
+    wave = synth_clips(n_tr + n_va, L=220500, seed=23, device="cuda")
+    pipe = DevicePipeline(n_mels=64, vocab_size=1024, niter=5, clustering_batch_size=1000, spectrogram_batch_size=500)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = pipe.run(wave[:n_tr], wave[n_tr:])
+        host = wave.cpu().pin_memory()
+        del wave
+        got = pipe.run_streaming(host[:n_tr], host[n_tr:], chunk_clips=500)
+    assert host.is_pinned() and len(got.kmeans_stats) == 3
+    assert torch.equal(got.centroids.view(torch.int32), ref.centroids.view(torch.int32))
+    assert got.tokens_train.numel() == n_tr * 1723 and got.tokens_val.numel() == n_va * 1723
+    assert torch.equal(got.tokens_train, ref.tokens_train.cpu())
+    assert torch.equal(got.tokens_val, ref.tokens_val.cpu())
+
+
 def test_use_convolution_through_the_stage_classes(workdir, oracle, monkeypatch, tmp_path):
     """use_convolution=True (random-init Conv1d(1, 10, 3) along the mel axis -> d = 640) through
     ClusterCreator -> SpecTokenizer on files, against the oracle fed the same convolved frames (d = 640 takes the
