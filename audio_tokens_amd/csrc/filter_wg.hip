@@ -10,8 +10,13 @@
 //
 //   * the needed groups of all its tiles are merged into ONE list (group | tile bits);
 //   * a group's hi fragments + |c|^2 (d/16 KiB + 256 B) are staged in LDS ONCE per workgroup by LDS-DMA
-//     (global_load_lds_dwordx4, every wave issues one 1 KiB piece), in a ring of three stages: the stage being
-//     multiplied, and two in flight behind counted s_waitcnt vmcnt -- the L2 latency is never waited for;
+//     (global_load_lds_dwordx4, every wave issues one 1 KiB piece), in a ring of RING stages: the stage being
+//     multiplied and RING - 2 in flight behind a counted s_waitcnt vmcnt.  The depth is what the L2 -> LDS path needs:
+//     it delivers ~70 GB/s per CU only with ~70 KiB in flight per CU (MI355X_MICROARCH.md, gather into LDS); with a
+//     ring of three (26 KiB in flight per CU) the first version of this kernel ran at 1.3 ms where the one-wave
+//     kernel took 0.95.  The lo parts of the rows therefore do NOT sit in LDS (32 KiB per workgroup) as in
+//     filter.hip: the few tiles that have marked pairs re-read their rows (they are still in L2 / the Infinity
+//     Cache) and split them again;
 //   * tiles are dealt to the waves round robin (wave w owns tiles w and w + 4): the tiles that need a group are
 //     mostly neighbours in the visiting order, so a visit's work spreads over the waves;
 //   * the walk multiplies hi*hi only (4 MFMAs per tile and group) and screens the result against a threshold that
@@ -31,7 +36,6 @@ namespace {
 using namespace atf;
 
 constexpr int WGT = 256;     // four waves
-constexpr int RING = 3;
 
 template <int N>
 __device__ __forceinline__ void wait_vm_and_barrier() {
@@ -56,9 +60,11 @@ struct Carve {
     static constexpr int NS = D / 16;
     static constexpr int NT = 4 * NB;                                  // tiles of the workgroup
     static constexpr size_t STAGE = (size_t)NS * 1024 + 256;           // hi fragments, |c|^2 + indices
+    // three 256-row workgroups (NB = 2) or four 128-row workgroups (NB = 1) per CU: ~46 / ~31 KiB each;
+    // three batches of visits in the ring
+    static constexpr int RING = NB == 2 ? 9 : 6;
     static constexpr size_t ring = 0;
-    static constexpr size_t xl = ring + RING * STAGE;                  // lo parts of the rows [NT][NS][64] half8
-    static constexpr size_t need = xl + (size_t)NT * NS * 1024;        // need masks [NT][8] u64
+    static constexpr size_t need = ring + RING * STAGE;                // need masks [NT][8] u64
     static constexpr size_t glist = need + (size_t)NT * 64;            // merged list, 512 u32
     static constexpr size_t refb = glist + 2048;                       // marked pairs [NT][16] u32 (bit per group)
     static constexpr size_t stash = refb + (size_t)NT * 64;            // per tile [4][32] words: tau, row, gbd, hint
@@ -75,6 +81,7 @@ assign_f16filter_wg_kernel(const float* __restrict__ X, long n, const unsigned c
     using L = Carve<D, NB>;
     constexpr int NS = L::NS;
     constexpr int NT = L::NT;
+    constexpr int RING = L::RING;
     constexpr size_t GB = group_bytes(D);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
@@ -90,6 +97,14 @@ assign_f16filter_wg_kernel(const float* __restrict__ X, long n, const unsigned c
     half8 xh[NB][NS];
     float thr[NB], cap0[NB];
     unsigned st_needed = 0, st_total = 0;
+#ifdef AT_WG_STAMPS   // diagnostic build: where a wave's cycles go (replaces the statistics record; results unchanged)
+    unsigned long long tst[6];
+    unsigned long long t_wait = 0, t_comp = 0;
+#define AT_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); tst[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+    AT_STAMP(0);
+#else
+#define AT_STAMP(i) do {} while (0)
+#endif
 
     // ---- prologue: this wave's tiles (w, w + 4) exactly as filter.hip's fused pre-pass does them ---------------
     unsigned long long need[NB][8];
@@ -152,22 +167,15 @@ assign_f16filter_wg_kernel(const float* __restrict__ X, long n, const unsigned c
         // Elkan radius (2R); rows without a guess need every group, positions past n none
         const float mtau = !live ? -1.0f
                                  : (has ? 2.0f * sqrtf(dh + delta) * (1.0f + 4.0f * 5.9604645e-8f) + 1e-30f : __builtin_inff());
-        // fp16 split of the row: hi parts stay in registers (the MFMA B operand), lo parts wait in LDS
-        half8* xl_lds = reinterpret_cast<half8*>(lds + L::xl) + (size_t)T * NS * 64;
+        // fp16 split of the row: the hi parts stay in registers (the MFMA B operand); the lo parts are formed again
+        // by the refinement, for the tiles that need them
 #pragma unroll
         for (int s = 0; s < NS; s++) {
-            const f32x4 u = xu[s], v = xv[s];
-            half8 xlo;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const _Float16 hu = (_Float16)u[e];
-                xh[b][s][e] = hu;
-                xlo[e] = (_Float16)(u[e] - (float)hu);
-                const _Float16 hv = (_Float16)v[e];
-                xh[b][s][4 + e] = hv;
-                xlo[4 + e] = (_Float16)(v[e] - (float)hv);
+                xh[b][s][e] = (_Float16)xu[s][e];
+                xh[b][s][4 + e] = (_Float16)xv[s][e];
             }
-            xl_lds[s * 64 + lane] = xlo;
         }
         const float tau = __builtin_fmaf(tau_a, nrm * 1.001f + cnmax, tau_b);
         const float rho = screen ? __builtin_fmaf(rho_a, nrm * 1.001f + cnmax, rho_b) : __builtin_inff();
@@ -227,6 +235,7 @@ assign_f16filter_wg_kernel(const float* __restrict__ X, long n, const unsigned c
         }
         if (lane < 16) reinterpret_cast<uint32_t*>(lds + L::refb)[T * 16 + lane] = 0u;
     }
+    AT_STAMP(1);
     __syncthreads();
 
     // ---- one list for the workgroup: entry = group | (tile bits << 9) ------------------------------------------
@@ -262,69 +271,134 @@ assign_f16filter_wg_kernel(const float* __restrict__ X, long n, const unsigned c
         }
         if (w == 0) dma4(base + misc_off(D) + lane * 4, slot + (size_t)NS * 1024);
     };
-    uint32_t ve_cur = cnt > 0 ? glist[0] : 0u, ve_nxt = cnt > 1 ? glist[1] : 0u;
-    if (cnt > 0) stage(0, (unsigned)__builtin_amdgcn_readfirstlane((int)ve_cur));
-    if (cnt > 1) stage(1, (unsigned)__builtin_amdgcn_readfirstlane((int)ve_nxt));
-    int cur_slot = 0;                      // slot of visit i; visit i + 2 goes into the slot visit i - 1 has left
-    unsigned n_hh = 0;
+    // Visits go in batches of BATCH with ONE barrier per batch: the four waves' work differs from visit to visit (a
+    // visit has ~2.7 of the 8 tiles active) and a barrier per visit made every visit cost its slowest wave -- 1.3 ms
+    // for the sweep against 0.95 for round 2's kernel.  The ring holds three batches: the one being multiplied and
+    // two in flight (requested when the batch two before them has been left by every wave).
+    constexpr int BATCH = RING / 3;
     constexpr int PIECES = NS / 4;          // LDS-DMA instructions per wave and stage (wave 0: one more)
-    for (int i = 0; i < cnt; i++) {
-        const uint32_t ve_st = i + 2 < cnt ? glist[i + 2] : 0u;
-        if (i + 1 < cnt) {
-            if (w == 0) wait_vm_and_barrier<PIECES + 1>();
-            else wait_vm_and_barrier<PIECES>();
+    const int nbatch = (cnt + BATCH - 1) / BATCH;
+    auto issue_batch = [&](int k) {
+#pragma unroll
+        for (int v = 0; v < BATCH; v++) {
+            const int i = k * BATCH + v;
+            if (i < cnt) stage((k % 3) * BATCH + v, (unsigned)__builtin_amdgcn_readfirstlane((int)glist[i]));
+        }
+    };
+    AT_STAMP(2);
+    if (nbatch > 0) issue_batch(0);
+    if (nbatch > 1) issue_batch(1);
+    unsigned n_hh = 0;
+    for (int k = 0; k < nbatch; k++) {
+        uint32_t ve[BATCH];
+#pragma unroll
+        for (int v = 0; v < BATCH; v++) ve[v] = k * BATCH + v < cnt ? glist[k * BATCH + v] : 0u;
+        // batch k has landed when all but the pieces of batch k + 1 have -- if that one is complete (only the last
+        // batch can be short: in front of it everything is waited for)
+#ifdef AT_WG_STAMPS
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+#endif
+        if (k + 2 < nbatch) {
+            if (w == 0) wait_vm_and_barrier<BATCH * (PIECES + 1)>();
+            else wait_vm_and_barrier<BATCH * PIECES>();
         } else {
             wait_vm_and_barrier<0>();
         }
-        const int prev_slot = cur_slot == 0 ? RING - 1 : cur_slot - 1;
-        if (i + 2 < cnt) stage(prev_slot, (unsigned)__builtin_amdgcn_readfirstlane((int)ve_st));
-        const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)ve_cur);
-        ve_cur = ve_nxt;
-        ve_nxt = ve_st;
-        const unsigned char* slot = ring + (size_t)cur_slot * L::STAGE;
-        cur_slot = cur_slot == RING - 1 ? 0 : cur_slot + 1;
-        const unsigned mine = ((e >> (9 + w)) & 1u) | (NB == 2 ? (((e >> (13 + w)) & 1u) << 1) : 0u);
-        if (mine == 0) continue;
-        half8 ah[NS];
-        f32x4 cnv[4];
+#ifdef AT_WG_STAMPS
+        const unsigned long long tw1 = __builtin_amdgcn_s_memtime();
+        t_wait += tw1 - tw0;
+#endif
+        if (k + 2 < nbatch) issue_batch(k + 2);     // into the slots batch k - 1 has left
+#ifdef AT_WG_STAMPS
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long tw2 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
-        for (int s = 0; s < NS; s++) ah[s] = reinterpret_cast<const half8*>(slot)[s * 64 + lane];
-        const float* cnp = reinterpret_cast<const float*>(slot + (size_t)NS * 1024);
+        for (int v = 0; v < BATCH; v++) {
+            if (k * BATCH + v >= cnt) break;
+            const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)ve[v]);
+            const unsigned mine = ((e >> (9 + w)) & 1u) | (NB == 2 ? (((e >> (13 + w)) & 1u) << 1) : 0u);
+            if (mine == 0) continue;
+            const unsigned char* slot = ring + (size_t)((k % 3) * BATCH + v) * L::STAGE;
+            half8 ah[NS];
+            f32x4 cnv[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) cnv[q] = *reinterpret_cast<const f32x4*>(cnp + 8 * q + 4 * h);
-        const unsigned g = e & 511u;
+            for (int s = 0; s < NS; s++) ah[s] = reinterpret_cast<const half8*>(slot)[s * 64 + lane];
+            const float* cnp = reinterpret_cast<const float*>(slot + (size_t)NS * 1024);
 #pragma unroll
-        for (int b = 0; b < NB; b++) {
-            if (!((mine >> b) & 1u)) continue;     // wave-uniform
-            f32x16 a = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int q = 0; q < 4; q++) cnv[q] = *reinterpret_cast<const f32x4*>(cnp + 8 * q + 4 * h);
+            const unsigned g = e & 511u;
+            auto hihi = [&](int b) {
+                f32x16 a = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int s = 0; s < NS; s++) a = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[b][s], a, 0, 0, 0);
-            float P[16];
+                for (int s = 0; s < NS; s++) a = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[b][s], a, 0, 0, 0);
+                return a;
+            };
+            auto screen_tile = [&](int b, const f32x16& a) {
+                float P[16];
 #pragma unroll
-            for (int r = 0; r < 16; r++) P[r] = __builtin_fmaf(-2.0f, a[r], cnv[r >> 2][r & 3]);
-            const bool pass = __builtin_amdgcn_ballot_w64(min16(P) < thr[b]) != 0;
-            n_hh++;
-            if (pass && lane == 0) {
-                uint32_t* rb = reinterpret_cast<uint32_t*>(lds + L::refb) + (w + 4 * b) * 16;
-                rb[g >> 5] |= 1u << (g & 31);
+                for (int r = 0; r < 16; r++) P[r] = __builtin_fmaf(-2.0f, a[r], cnv[r >> 2][r & 3]);
+                const bool pass = __builtin_amdgcn_ballot_w64(min16(P) < thr[b]) != 0;
+                n_hh++;
+                if (pass && lane == 0) {
+                    uint32_t* rb = reinterpret_cast<uint32_t*>(lds + L::refb) + (w + 4 * b) * 16;
+                    rb[g >> 5] |= 1u << (g & 31);
+                }
+            };
+            if constexpr (NB == 2) {
+                if (mine == 3u) {   // both tiles: the second tile's MFMAs run while the first tile is screened
+                    const f32x16 a0 = hihi(0);
+                    const f32x16 a1 = hihi(1);
+                    screen_tile(0, a0);
+                    screen_tile(1, a1);
+                } else if (mine == 1u) {
+                    screen_tile(0, hihi(0));
+                } else {
+                    screen_tile(1, hihi(1));
+                }
+            } else {
+                screen_tile(0, hihi(0));
             }
         }
+#ifdef AT_WG_STAMPS
+        __builtin_amdgcn_sched_barrier(0);
+        t_comp += __builtin_amdgcn_s_memtime() - tw2;
+#endif
     }
+    AT_STAMP(3);
 
     // ---- the marked pairs: all three products, the triple as filter.hip keeps it -------------------------------
+    // Tile by tile (a tile's lo parts are formed when its first mark turns up and live in registers until its last):
+    // ONE fragment set; the next pair's fragments are requested as soon as this pair's MFMAs have been issued (they
+    // have read their operands by then) and arrive while the MFMAs run and the triple is updated.
     float b1[NB], b2[NB], b3[NB];
     unsigned i1[NB], i2[NB];
+    unsigned n_ref = 0;
 #pragma unroll
     for (int b = 0; b < NB; b++) {
         b1[b] = b2[b] = b3[b] = cap0[b];
         i1[b] = i2[b] = NONE;
-    }
-    unsigned n_ref = 0;
-    {
-        // (the marks are this wave's own stores: LDS operations of one wave execute in order)
-        const uint32_t* rb0 = reinterpret_cast<const uint32_t*>(lds + L::refb) + w * 16;
-        const uint32_t* rb1 = reinterpret_cast<const uint32_t*>(lds + L::refb) + (w + 4) * 16;
-        auto load_pair = [&](unsigned g, half8 (&ah)[NS], half8 (&al)[NS], f32x4 (&cnv)[4]) {
+        const int T = w + 4 * b;
+        const uint32_t* rb = reinterpret_cast<const uint32_t*>(lds + L::refb) + T * 16;   // (this wave's own stores)
+        int wi = 0;
+        uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)rb[0]);
+        auto next_mark = [&](unsigned& g) -> bool {   // wave-uniform
+            for (;;) {
+                if (m != 0) {
+                    const int bit = __builtin_ctz(m);
+                    g = (unsigned)(wi * 32 + bit);
+                    m &= m - 1u;
+                    return true;
+                }
+                if (++wi >= 16 || wi * 32 >= ng) return false;
+                m = (uint32_t)__builtin_amdgcn_readfirstlane((int)rb[wi]);
+            }
+        };
+        unsigned gC = 0, gN = 0;
+        bool have = next_mark(gC);
+        if (!have) continue;
+        auto load_frags = [&](unsigned g, half8 (&ah)[NS], half8 (&al)[NS]) {
             const unsigned char* base = img + (size_t)g * GB;
             const half8* fh = reinterpret_cast<const half8*>(base);
             const half8* fl = reinterpret_cast<const half8*>(base + lo_off(D));
@@ -333,76 +407,76 @@ assign_f16filter_wg_kernel(const float* __restrict__ X, long n, const unsigned c
                 ah[s] = fh[s * 64 + lane];
                 al[s] = fl[s * 64 + lane];
             }
-            const float* cnp = reinterpret_cast<const float*>(base + misc_off(D));
+        };
+        auto load_cn = [&](unsigned g, f32x4 (&cnv)[4]) {
+            const float* cnp = reinterpret_cast<const float*>(img + (size_t)g * GB + misc_off(D));
 #pragma unroll
             for (int q = 0; q < 4; q++) cnv[q] = *reinterpret_cast<const f32x4*>(cnp + 8 * q + 4 * h);
         };
-        auto refine_pair = [&](unsigned g, unsigned which, const half8 (&ah)[NS], const half8 (&al)[NS], const f32x4 (&cnv)[4]) {
+        half8 ah[NS], al[NS];
+        f32x4 cnC[4], cnN[4];
+        load_frags(gC, ah, al);
+        load_cn(gC, cnC);
+        // the lo parts of this tile's rows: v - fp16(v), rounded to fp16 (the rows are re-read: L2 / Infinity Cache)
+        half8 xl[NS];
+        {
+            const unsigned r = reinterpret_cast<const unsigned*>(lds + L::stash)[(size_t)T * 128 + 32 + j];
+            const f32x4* p = reinterpret_cast<const f32x4*>(X + (size_t)r * D);
 #pragma unroll
-            for (int b = 0; b < NB; b++) {
-                if (!((which >> b) & 1u)) continue;
-                const half8* xl_lds = reinterpret_cast<const half8*>(lds + L::xl) + (size_t)(w + 4 * b) * NS * 64;
-                f32x16 a = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int s = 0; s < NS; s++) {
+                const f32x4 u = p[4 * s + 2 * h], v = p[4 * s + 2 * h + 1];
 #pragma unroll
-                for (int s = 0; s < NS; s++) a = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[b][s], a, 0, 0, 0);
-#pragma unroll
-                for (int s = 0; s < NS; s++) {
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], xh[b][s], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xl_lds[s * 64 + lane], a, 0, 0, 0);
-                }
-                float P[16];
-#pragma unroll
-                for (int r = 0; r < 16; r++) P[r] = __builtin_fmaf(-2.0f, a[r], cnv[r >> 2][r & 3]);
-                n_ref++;
-                if (__builtin_amdgcn_ballot_w64(min16(P) < b3[b]) != 0) {
-                    float v1 = b1[b], v2 = b2[b], v3 = b3[b];
-                    unsigned j1 = i1[b], j2 = i2[b];
-                    const unsigned base = g * 32u + 4u * h;
-#pragma unroll
-                    for (int r = 0; r < 16; r++) insert3(P[r], base + (unsigned)((r & 3) + 8 * (r >> 2)), v1, v2, v3, j1, j2);
-                    b1[b] = v1; b2[b] = v2; b3[b] = v3;
-                    i1[b] = j1; i2[b] = j2;
+                for (int e = 0; e < 4; e++) {
+                    xl[s][e] = (_Float16)(u[e] - (float)(_Float16)u[e]);
+                    xl[s][4 + e] = (_Float16)(v[e] - (float)(_Float16)v[e]);
                 }
             }
-        };
-        // walk the marks in group order, the next pair's fragments requested while this one multiplies
-        half8 ahA[NS], alA[NS], ahB[NS], alB[NS];
-        f32x4 cnA[4], cnB[4];
-        int wi = 0;
-        uint32_t m0 = rb0[0], m1 = NB == 2 ? rb1[0] : 0u;
-        auto next_mark = [&](unsigned& g, unsigned& which) -> bool {   // wave-uniform
-            for (;;) {
-                const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)(m0 | m1));
-                if (u != 0) {
-                    const int bit = __builtin_ctz(u);
-                    const uint32_t f0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)m0);
-                    const uint32_t f1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)m1);
-                    g = (unsigned)(wi * 32 + bit);
-                    which = ((f0 >> bit) & 1u) | (((f1 >> bit) & 1u) << 1);
-                    m0 &= ~(1u << bit);
-                    m1 &= ~(1u << bit);
-                    return true;
-                }
-                if (++wi >= 16 || wi * 32 >= ng) return false;
-                m0 = rb0[wi];
-                m1 = NB == 2 ? rb1[wi] : 0u;
+        }
+        while (have) {
+            // hi*hi first, as the walk formed it; then the two lo products
+            f32x16 a = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < NS; s++) a = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xh[b][s], a, 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], xh[b][s], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], xl[s], a, 0, 0, 0);
             }
-        };
-        unsigned gA = 0, wA = 0, gB = 0, wB = 0;
-        bool haveA = next_mark(gA, wA);
-        if (haveA) load_pair(gA, ahA, alA, cnA);
-        while (haveA) {
-            const bool haveB = next_mark(gB, wB);
-            if (haveB) load_pair(gB, ahB, alB, cnB);
-            refine_pair(gA, wA, ahA, alA, cnA);
-            if (!haveB) break;
-            haveA = next_mark(gA, wA);
-            if (haveA) load_pair(gA, ahA, alA, cnA);
-            refine_pair(gB, wB, ahB, alB, cnB);
+            const bool more = next_mark(gN);
+            if (more) {
+                load_frags(gN, ah, al);
+                load_cn(gN, cnN);
+            }
+            float P[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) P[r] = __builtin_fmaf(-2.0f, a[r], cnC[r >> 2][r & 3]);
+            n_ref++;
+            if (__builtin_amdgcn_ballot_w64(min16(P) < b3[b]) != 0) {
+                float v1 = b1[b], v2 = b2[b], v3 = b3[b];
+                unsigned j1 = i1[b], j2 = i2[b];
+                const unsigned base = gC * 32u + 4u * h;
+#pragma unroll
+                for (int r = 0; r < 16; r++) insert3(P[r], base + (unsigned)((r & 3) + 8 * (r >> 2)), v1, v2, v3, j1, j2);
+                b1[b] = v1; b2[b] = v2; b3[b] = v3;
+                i1[b] = j1; i2[b] = j2;
+            }
+            have = more;
+            gC = gN;
+#pragma unroll
+            for (int q = 0; q < 4; q++) cnC[q] = cnN[q];
         }
     }
 
+    AT_STAMP(4);
+#ifdef AT_WG_STAMPS
+    // record (units of 16 cycles): prologue + list, waits of the walk (barrier + vmcnt), the walk's work (DMA issue excluded), refinement
+    if (lane == 0 && blk_stats)
+        blk_stats[(size_t)blockIdx.x * 4 + w] = make_uint4((unsigned)((tst[2] - tst[0]) >> 4), (unsigned)(t_wait >> 4), (unsigned)(t_comp >> 4),
+                                                           (unsigned)((tst[4] - tst[3]) >> 4));
+    (void)st_needed; (void)st_total; (void)n_hh; (void)n_ref;
+#else
     if (lane == 0 && blk_stats) blk_stats[(size_t)blockIdx.x * 4 + w] = make_uint4(st_needed, st_total, n_hh, n_ref);
+#endif
 
     // ---- epilogue: merge the half-waves, settle or list (filter.hip) -------------------------------------------
     auto slot_id = [&](unsigned slot) {
