@@ -88,7 +88,6 @@ struct at_debug {
     int visit_bits;       // AT_VISIT_BITS       distance bits of the visiting-order key (0..8; default 8)
     int filter_stats;     // AT_FILTER_STATS     1 = the sweeps count accumulators / tiles for at_prune_stats, at_filter_stats
     int accum_buckets;    // AT_ACCUM_BUCKETS    0 = member lists by radix sort (the only form for k > 16 384)
-    int filter_wg;        // AT_FILTER_WG        0 = d = 64 exact sweeps by the one-wave-per-workgroup kernel of round 2
     int filter_timing;    // AT_FILTER_TIMING    1 = exact calls bracket their stage-1 kernel with two timing events (bench.py; off in the product)
 };
 

@@ -1175,27 +1175,6 @@ int at_filter_sweep(at_ctx* ctx, const float* x, int64_t n, int d, const float* 
     // exact calls (collect) and guess generators are separate instantiations: the guess path's code
     // would otherwise cost the exact sweep registers it does not have
     const dim3 grid64((unsigned)((n + 63) / 64));
-    // d = 64 exact fused sweeps: four waves around one fragment stream (filter_wg.hip); switch filter_wg = 0 keeps the
-    // one-wave-per-workgroup kernels below (A/B aid, and still the form of d = 128 and of the guess generators)
-    const bool use_wg = fused && d == 64 && ctx->dbg.filter_wg != 0 && nbv != 4;
-    if (use_wg) {
-        const int tpw = nbv ? (nbv == 1 ? 1 : 2) : (n <= (int64_t)1 << 19 ? 1 : 2);
-        const unsigned n_wgw = (unsigned)((n + 128 * tpw - 1) / (128 * tpw)) * 4u;   // one record per wave
-        if (ctx->dbg.filter_stats) {
-            blk_stats = static_cast<uint4*>(at_ws(ctx, WS_FILTER_BLKSTATS, (size_t)n_wgw * sizeof(uint4), stream));
-            if (!blk_stats) return AT_E_NOMEM;
-        }
-        const int rcw = at_filter_sweep_wg(ctx, x, n, d, img, ng, order, misc, ta, tb, ra, rb, screen, ids, amb_list, amb_aux,
-                                           approx_out, fp, blk_stats, amb_cap, tpw, stream);
-        if (rcw) return rcw;
-        if (timed) {
-            AT_HIP(hipEventRecord(tslot.ev[1], stream));
-            tslot.timed = 1;
-        }
-        if (blk_stats)
-            AT_LAUNCH(filter_stats_reduce_kernel, dim3(1), dim3(1024), 0, stream, blk_stats, n_wgw, fp.stats, misc);
-        return AT_OK;
-    }
     if (d == 128) {  // two tiles per wave: the fragment sets of d = 128 leave no registers for four
         if (fused) AT_FILTER_LAUNCH(128, 2, false, true, grid64);
         else if (collect) AT_FILTER_LAUNCH(128, 2, false, false, grid64);

@@ -1,5 +1,5 @@
-// filter_common.h -- what the kernels of the fp16-split filter share (filter.hip: one wave per workgroup;
-// filter_wg.hip: four waves around one fragment stream).  Not installed.
+// filter_common.h -- layout of the fp16 centroid image and the small helpers of the fp16-split filter (filter.hip).
+// Not installed.
 #pragma once
 #include "at_internal.h"
 
@@ -57,10 +57,3 @@ constexpr unsigned DIST_TODO = 0x7fc0deadu;  // a NaN no computed distance can b
 constexpr unsigned AMB_SUBLISTS = 64;      // the rows a sweep lists for the redo are appended to 64 sub-lists
 
 }  // namespace atf
-
-// filter_wg.hip: the exact fused sweep as 128- or 256-row workgroups around one fragment stream (d = 64)
-int at_filter_sweep_wg(at_ctx* ctx, const float* x, int64_t n, int d, const unsigned char* img, int ng,
-                       const uint32_t* order, unsigned* misc, float tau_a, float tau_b, float rho_a, float rho_b,
-                       int screen, int64_t* ids, uint32_t* amb_list, uint32_t* amb_aux, float* approx_out,
-                       const atf::FusedPrepass& fp, uint4* blk_stats, unsigned amb_cap, int tiles_per_wave,
-                       hipStream_t stream);

@@ -70,7 +70,6 @@ const DebugField kDebugFields[] = {
     {"filter_stats", "AT_FILTER_STATS", &at_debug::filter_stats, 0},
     {"visit_bits", "AT_VISIT_BITS", &at_debug::visit_bits, 8},
     {"filter_timing", "AT_FILTER_TIMING", &at_debug::filter_timing, 0},
-    {"filter_wg", "AT_FILTER_WG", &at_debug::filter_wg, 1},
 };
 }  // namespace
 

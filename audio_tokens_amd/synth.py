@@ -26,8 +26,10 @@ def _mix(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
-def clip_params(seed: int, clip_ids: np.ndarray):
-    """Per-clip parameters from a numpy Generator keyed by (seed, clip id)."""
+def clip_params(seed: int, clip_ids: np.ndarray, noisy: bool = False):
+    """Per-clip parameters from a numpy Generator keyed by (seed, clip id).  noisy: the harder stream of bench.py's
+    `hard_workload` -- the same draws, with the tones at a fifth of their amplitude under white noise of
+    sigma ~ LogU(0.05, 0.5): frames that cluster poorly."""
     n = len(clip_ids)
     ntone = np.zeros(n, np.int64)
     f0 = np.zeros((n, 4)); f1 = np.zeros((n, 4)); amp = np.zeros((n, 4)); ph = np.zeros((n, 4))
@@ -43,11 +45,14 @@ def clip_params(seed: int, clip_ids: np.ndarray):
         sigma[j] = np.exp(r.uniform(np.log(1e-4), np.log(1e-1)))
         z0[j] = r.random()
         zlen[j] = r.random() * 0.04  # ~2 % of all frames are digital silence (identical points)
+        if noisy:
+            amp[j] *= 0.2
+            sigma[j] = np.exp(np.log(0.05) + (np.log(sigma[j]) - np.log(1e-4)) / (np.log(1e-1) - np.log(1e-4)) * (np.log(0.5) - np.log(0.05)))
     return dict(f0=f0, f1=f1, amp=amp, ph=ph, sigma=sigma, z0=z0, zlen=zlen)
 
 
 def synth_clips(n_clips: int, L: int = 220500, seed: int = 4242, first_clip: int = 0, sr: int = 22050,
-                device="cpu", chunk: int = 256, out: torch.Tensor | None = None) -> torch.Tensor:
+                device="cpu", chunk: int = 256, out: torch.Tensor | None = None, noisy: bool = False) -> torch.Tensor:
     """-> float32 [n_clips, L] in [-1, 1] on `device`."""
     device = torch.device(device)
     if out is None:
@@ -58,7 +63,7 @@ def synth_clips(n_clips: int, L: int = 220500, seed: int = 4242, first_clip: int
     for c0 in range(0, n_clips, chunk):
         c1 = min(n_clips, c0 + chunk)
         ids = np.arange(first_clip + c0, first_clip + c1)
-        p = clip_params(seed, ids)
+        p = clip_params(seed, ids, noisy)
         P = {k: torch.from_numpy(np.asarray(v)).to(device) for k, v in p.items()}
         w = torch.zeros((c1 - c0, L), dtype=torch.float64, device=device)
         for j in range(4):

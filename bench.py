@@ -57,32 +57,58 @@ CONFIGS = {
 }
 
 
+def cpu_logmel_torch(wave, n_mels, hop, n_fft=512, sr=22050):
+    """SURVEY.md section 8d's CPU log-mel: torch.stft the way torchaudio's MelSpectrogram calls it (periodic Hann,
+    center, reflect padding, power 2), the HTK filterbank, 10 log10(clamp) -- fp32 on torch's CPU threads."""
+    from audio_tokens_amd.backend import HostHelpers
+    fb = torch.from_numpy(HostHelpers().mel_filterbank(sr, n_fft, n_mels))
+    win = torch.hann_window(n_fft, periodic=True)
+    out = []
+    for c0 in range(0, wave.shape[0], 32):
+        st = torch.stft(wave[c0:c0 + 32], n_fft, hop_length=hop, win_length=n_fft, window=win, center=True,
+                        pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
+        power = st.abs().pow(2.0)                                   # [clips, n_freq, T]
+        mel = torch.matmul(power.transpose(1, 2), fb)               # [clips, T, n_mels]
+        out.append(10.0 * torch.log10(torch.clamp(mel, min=1e-10)))
+    return torch.cat(out).reshape(-1, n_mels).numpy()               # frame-major, as the k-means stage wants it
+
+
 def cpu_baseline(n_mels, vocab, L, hop, seed, clips, niter):
-    """The oracle (CPU restatement, kind="port") timed on this box's host cores on a bounded
-    sample of the same workload.  Only this function touches oracle/."""
+    """The CPU path timed on this box's host cores on a bounded sample of the same workload (kind="port": faiss and
+    torchaudio are not installable here).  Log-mel: torch.stft-based, fp32, torch's CPU threads (SURVEY.md section 8d);
+    the oracle's double-precision log-mel is timed beside it.  K-means and tokenise: the oracle (C, OpenMP).
+    Only this function touches oracle/."""
     import oracle
     from audio_tokens_amd.synth import synth_clips
     oracle.build()
-    wave = synth_clips(clips, L=L, seed=seed, first_clip=0, device="cpu").numpy()
+    wave_t = synth_clips(clips, L=L, seed=seed, first_clip=0, device="cpu")
     t0 = time.perf_counter()
-    specs = [oracle.logmel(w, n_mels=n_mels, hop=hop) for w in wave]
-    x = np.concatenate([s.T for s in specs], axis=0).astype(np.float32)
-    x = oracle.l2norm_rows(x)
+    x = cpu_logmel_torch(wave_t, n_mels, hop)
+    x = oracle.l2norm_rows(np.ascontiguousarray(x, dtype=np.float32))
     t1 = time.perf_counter()
     r = oracle.kmeans_train(x, vocab, niter=niter)
     c = oracle.l2norm_rows(r.centroids)
     t2 = time.perf_counter()
     oracle.assign(x, c)
     t3 = time.perf_counter()
+    wave = wave_t.numpy()
+    specs = [oracle.logmel(w, n_mels=n_mels, hop=hop) for w in wave[:max(1, clips // 4)]]
+    t4 = time.perf_counter()
+    del specs
     frames = x.shape[0]
     return {
         "value": frames / (t3 - t0),
         "unit": "frames/s",
         "cores": oracle.num_threads(),
+        "torch_threads": torch.get_num_threads(),
+        "os_cpu_count": os.cpu_count(),
         "kind": "port",
-        "sample": (f"{clips} clips ({frames} frames) of the same synthetic stream: log-mel, one Kmeans.train "
-                   f"(k={vocab}, niter={niter}), tokenise; "
-                   f"seconds: logmel {t1 - t0:.2f}, kmeans {t2 - t1:.2f}, tokenise {t3 - t2:.2f}; "
+        "sample": (f"{clips} clips ({frames} frames) of the same synthetic stream: torch.stft log-mel (fp32, {torch.get_num_threads()} "
+                   f"torch threads), then the oracle with {oracle.num_threads()} OpenMP threads: one Kmeans.train (k={vocab}, niter={niter} "
+                   f"-- the GPU step runs 60 Lloyd sweeps over 2.1 M rows per 43 M frames, i.e. 2.9 sweeps per frame, so 3 "
+                   f"iterations over the sample's frames do the same work per frame) and tokenise; "
+                   f"seconds: logmel {t1 - t0:.2f}, kmeans {t2 - t1:.2f}, tokenise {t3 - t2:.2f}; the oracle's own "
+                   f"double-precision log-mel takes {(t4 - t3) * clips / max(1, clips // 4):.2f} s for the same clips; "
                    f"host has {os.cpu_count()} logical cores"),
     }
 
@@ -101,6 +127,7 @@ def main():
     ap.add_argument("--clip-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-floor", action="store_true", help="skip the untimed dense run (dense_floor / verified = null)")
+    ap.add_argument("--no-hard-workload", action="store_true", help="skip the noise-dominated workload (hard_workload = null)")
     ap.add_argument("--cpu-clips", type=int, default=256)
     ap.add_argument("--host-waves", action="store_true",
                     help="also time DevicePipeline.run_streaming on pinned host copies of the same waveforms and report it "
@@ -223,6 +250,11 @@ def main():
     stage = pipe.run(wave_tr, wave_va, timing=True).stage_seconds
     _, _, _, _, f_tiles, f_refined = be.filter_stats(timing=True)
     f_tiles, f_refined = f_tiles * args.steps, f_refined * args.steps
+    stage_all = None
+    if dist is not None:   # every rank's split, for the scaling post-mortem
+        assert dist.get_world_size() == world == int(os.environ["WORLD_SIZE"]), "process group size != WORLD_SIZE"
+        stage_all = [None] * world
+        dist.all_gather_object(stage_all, {k2: round(v2, 6) for k2, v2 in stage.items()})
     needed, total = be.prune_stats()
     be.debug_set("filter_stats", 0)
 
@@ -358,10 +390,12 @@ def main():
             "frames_per_step": frames_per_step, "parallelism": f"dp{world}",
         },
         "stage_seconds": stage,
+        "stage_seconds_per_rank": stage_all,
         "warmup_step_ms": warm_ms,
         "traced_step_ms": traced_ms,
         "verified": verified,
         "dense_floor": dense_floor,
+        "hard_workload": None,
         "roofline": roofline,
         "comm": comm,
     }
@@ -376,6 +410,27 @@ def main():
         out["pcie_inclusive"] = {"value": frames_per_step / world / dt * world, "unit": "frames/s", "ms_per_step": dt * 1e3,
                                  "note": "waveforms in pinned host memory, streamed in 5000-clip chunks; frames kept only per "
                                          "k-means batch and recomputed for tokenise; tokens returned to the host"}
+    # ---- a harder stream: noise-dominated clips (tones at a fifth of their amplitude under sigma 0.05-0.5) ------
+    # The pruning and the filter feed on structure in the frames; `dense_floor` is the rate with none of it.  This
+    # is a midpoint: the same step on clips that cluster poorly, one warm-up and one timed run, outside `value`.
+    if not args.no_hard_workload:
+        hw_tr = synth_clips(n_tr, L=L, seed=seed, first_clip=rank * n_tr, device=device, out=wave_tr, noisy=True)
+        hw_va = synth_clips(n_va, L=L, seed=seed, first_clip=world * n_tr + rank * n_va, device=device, out=wave_va, noisy=True)
+        pipe.run(hw_tr, hw_va)
+        barrier()
+        t0 = time.perf_counter()
+        hres = pipe.run(hw_tr, hw_va)
+        barrier()
+        ht = time.perf_counter() - t0
+        if dist is not None:
+            tm = torch.tensor([ht], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            ht = float(tm.item())
+        out["hard_workload"] = {"value": frames_per_step / ht, "unit": "frames/s", "ms_per_step": ht * 1e3,
+                "note": "the same step on noise-dominated clips (synth_clips(noisy=True): tone amplitudes x 0.2, white noise "
+                        "sigma ~ LogU(0.05, 0.5)); one warm-up and one timed run, outside the timed region of `value`"}
+        del hres
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n_mels, vocab, L, hop, seed, args.cpu_clips, niter=3)
     else:

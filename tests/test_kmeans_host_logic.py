@@ -96,6 +96,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _cuts(n, world):
+    """Uneven contiguous blocks of n rows for `world` ranks (rank order = row order, as the sharded k-means assumes)."""
+    w = np.arange(1, world + 1, dtype=np.float64) ** 0.5 + 0.37
+    edges = np.concatenate([[0], np.floor(np.cumsum(w / w.sum()) * n).astype(np.int64)])
+    edges[-1] = n
+    return edges
+
+
 def _worker(rank, world, port, case, q, exchange="auto"):
     import sys
     sys.path.insert(0, str(Path(__file__).resolve().parent))
@@ -116,6 +124,14 @@ def _worker(rank, world, port, case, q, exchange="auto"):
                 km = Kmeans(64, 64, niter=20, distributed=True, backend=OracleBackend())
                 km.exchange = exchange
                 km.train(local)
+            elif case == "many":   # any world size: uneven blocks of the subsampled case, cold start then warm start
+                x = g["c_x"]
+                e = _cuts(len(x), world)
+                local = x[e[rank]:e[rank + 1]]
+                km = Kmeans(8, 64, niter=5, distributed=True, backend=OracleBackend())
+                km.exchange = exchange
+                km.train(local, init_centroids=g["c_init"])
+                km.train(local[: len(local) * 3 // 4], init_centroids=km.centroids)
             else:  # subsampled: 20000 rows, k=64 -> 16384 rows kept, spread over both ranks
                 x, cut = g["c_x"], 12345
                 local = x[:cut] if rank == 0 else x[cut:]
@@ -152,6 +168,36 @@ def test_sharded_kmeans_gloo_world2(case, exchange, oracle):
             warnings.simplefilter("ignore")
             r = oracle.kmeans_train(g["c_x"], 64, niter=5, init_centroids=g["c_init"], shard=shard, n_shards=2)
         assert np.array_equal(bits(res[0][1]), bits(r.centroids))
+
+
+@pytest.mark.parametrize("world,exchange", [(4, "gather"), (4, "scatter"), (8, "gather"), (8, "scatter")])
+def test_sharded_kmeans_gloo_world4_and_8(world, exchange, oracle):
+    """The N-GPU form at N = 4 and 8: uneven row blocks, the subsample permutation over the global
+    row index, a cold-started and a warm-started training -- every rank ends with the bits of the oracle's n_shards mode
+    (partials added in ascending shard order), in both forms of the exchange."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, "many", q, exchange)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    g = np.load(G / "kmeans.npz")
+    x = g["c_x"]
+    e = _cuts(len(x), world)
+    shard = (np.searchsorted(e, np.arange(len(x)), side="right") - 1).astype(np.int32)
+    keep = np.concatenate([np.arange(e[r], e[r] + (e[r + 1] - e[r]) * 3 // 4) for r in range(world)])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r1 = oracle.kmeans_train(x, 64, niter=5, init_centroids=g["c_init"], shard=shard, n_shards=world)
+        r2 = oracle.kmeans_train(x[keep], 64, niter=5, init_centroids=r1.centroids, shard=shard[keep], n_shards=world)
+    for rank, cent, nsplit, obj in res:
+        assert np.array_equal(bits(cent), bits(r2.centroids)), f"rank {rank} differs from the oracle's {world}-shard result"
+        assert nsplit == list(r2.nsplit)
+        np.testing.assert_allclose(obj, r2.obj, rtol=2e-5)      # (the objective is a statistic summed in another order: DESIGN.md section 2)
 
 
 def test_prefetch_preserves_order_and_errors():
