@@ -387,15 +387,19 @@ class HipBackend(HostHelpers):
                                                    self._stream()))
         return order, hs
 
-    def visit_order_beside(self, ids, dis, k):
+    def visit_order_beside(self, ids, dis, k, sum_out=None):
         """visit_order on a stream of its own (it has its own sort buffers): the caller's stream goes on at
-        once and must call the returned function before it uses the result."""
+        once and must call the returned function before it uses the result.  sum_out (float64 [1] view): the
+        objective sum_i dis[i] is queued on that stream too -- nothing on the caller's stream needs it before the join."""
         main = torch.cuda.current_stream(self.device)
         side = getattr(self, "_order_stream", None)
         if side is None:
             side = self._order_stream = torch.cuda.Stream(self.device)
         side.wait_stream(main)                 # ids / dis are complete on the caller's stream
         with torch.cuda.stream(side):
+            if sum_out is not None:
+                self.sum_f64(dis, out=sum_out)
+                sum_out.record_stream(side)
             out = self.visit_order(ids, dis, k)
 
         def join(out=out, ids=ids, dis=dis):   # (ids / dis are kept alive until the sort has been waited for)

@@ -122,6 +122,7 @@ struct at_ctx {
   // 32x32 tiles multiplied (hi*hi) / refined (lo products too), exact calls
     hipStream_t side_stream;             // centroid_accum: long member lists beside the short ones
     hipEvent_t side_ev[2];
+    hipEvent_t side_ev2;                 // behind the segment offsets computed beside the sort (centroid_accum, radix path)
     int defer_join, join_pending;        // at_centroid_accum_defer / at_centroid_accum_join
     int buckets_k;                       // table size WS_BUCKETS was last zeroed for
     int long_pred_k;                     // table size WS_LONG_PRED was last used with

@@ -177,6 +177,7 @@ void at_destroy(at_ctx* ctx) {
         for (int i = 0; i < 2; i++)
             if (fs.ev[i]) (void)AT_HIP_TOLERATE(hipEventDestroy(fs.ev[i]));
     }
+    if (ctx->side_ev2) (void)AT_HIP_TOLERATE(hipEventDestroy(ctx->side_ev2));
     if (ctx->side_stream) (void)AT_HIP_TOLERATE(hipStreamDestroy(ctx->side_stream));
     if (ctx->mt_ready) (void)AT_HIP_TOLERATE(hipEventDestroy(ctx->mt_ready));
     if (ctx->sum_ev) (void)AT_HIP_TOLERATE(hipEventDestroy(ctx->sum_ev));

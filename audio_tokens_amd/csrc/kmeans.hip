@@ -100,12 +100,16 @@ __global__ void __launch_bounds__(WG) centroid_accum_kernel(const float* __restr
 #pragma unroll
     for (int v = 0; v < VEC; v++) acc[v] = 0.0f;
 
-    // Rows are fetched eight at a time into one of two register sets: the loads of batch i+1 are in flight while
+    // Rows are fetched RB at a time into one of two register sets: the loads of batch i+1 are in flight while
     // batch i is added (in member order: one dependent chain per feature, as the contract says), and the member
-    // indices of the next 64 rows are fetched while this block of 64 is summed (262 -> 215 us at 2 M x 64).
-    auto fetch = [&](uint32_t mine, uint32_t m, uint32_t cnt, float (&t)[8][VEC]) {
+    // indices of the next 64 rows are fetched while this block of 64 is summed.  A list is one wave's sequential
+    // walk, so the kernel lasts as long as its longest lists (up to 2048 members): what bounds those is how many
+    // row reads the wave keeps in flight -- 16 per set (32 in flight) instead of round 2's 8: 168 -> see DESIGN us
+    // at 2 M x 64.
+    constexpr int RB = VEC == 4 ? 8 : 16;
+    auto fetch = [&](uint32_t mine, uint32_t m, uint32_t cnt, float (&t)[RB][VEC]) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < RB; u++) {
             const uint32_t src = __builtin_amdgcn_readlane(mine, (m + u) & 63);
             const bool ok = (m + u < cnt) && live;
             if constexpr (VEC == 4) {
@@ -119,9 +123,9 @@ __global__ void __launch_bounds__(WG) centroid_accum_kernel(const float* __restr
             }
         }
     };
-    auto add = [&](uint32_t m, uint32_t cnt, const float (&t)[8][VEC]) {
+    auto add = [&](uint32_t m, uint32_t cnt, const float (&t)[RB][VEC]) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < RB; u++) {
             if (m + u < cnt) {  // wave-uniform: the tail adds nothing at all
 #pragma unroll
                 for (int v = 0; v < VEC; v++) acc[v] += t[u][v];
@@ -133,14 +137,14 @@ __global__ void __launch_bounds__(WG) centroid_accum_kernel(const float* __restr
         const uint32_t cnt = min(64u, end - base);
         const uint32_t mine = mine_next;
         if (base + 64 < end) mine_next = lane < min(64u, end - base - 64) ? order[base + 64 + lane] : 0u;
-        float tA[8][VEC], tB[8][VEC];
+        float tA[RB][VEC], tB[RB][VEC];
         fetch(mine, 0, cnt, tA);
-        for (uint32_t m = 0; m < cnt; m += 16) {
-            if (m + 8 < cnt) fetch(mine, m + 8, cnt, tB);
+        for (uint32_t m = 0; m < cnt; m += 2 * RB) {
+            if (m + RB < cnt) fetch(mine, m + RB, cnt, tB);
             add(m, cnt, tA);
-            if (m + 8 < cnt) {
-                if (m + 16 < cnt) fetch(mine, m + 16, cnt, tA);
-                add(m + 8, cnt, tB);
+            if (m + RB < cnt) {
+                if (m + 2 * RB < cnt) fetch(mine, m + 2 * RB, cnt, tA);
+                add(m + RB, cnt, tB);
             }
         }
     }
@@ -870,6 +874,7 @@ int at_centroid_accum_f32(at_ctx* ctx, const float* x, int64_t n, int d, const i
     // (decided before anything is queued: the early lists of the long clusters run on the side stream beside the sort)
     const bool al_x = at_aligned16(x);
     const bool early_ok = d % 4 == 0 && al_x && n > 2048;
+    bool offsets_beside = false;
     if (early_ok) {
         if (!ctx->side_stream) {
             AT_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
@@ -894,6 +899,30 @@ int at_centroid_accum_f32(at_ctx* ctx, const float* x, int64_t n, int d, const i
         AT_HIP(hipEventRecord(ctx->side_ev[0], stream));          // ids (and the marks) are ready
         AT_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->side_ev[0], 0));
         hipStream_t ss = ctx->side_stream;
+        if (k <= 16384) {
+            // The segment offsets do not need the sort: counts per cluster (LDS histogram per row block) and their scan
+            // -- the first two kernels of the bucket path -- run beside it, instead of 8193 binary searches over the
+            // sorted keys behind it (40 us on the critical path of a 2 M-row iteration).
+            const bool fresh = ctx->ws_bytes[WS_BUCKETS] < ((size_t)3 * k + 8) * 4;
+            unsigned* bw = static_cast<unsigned*>(at_ws(ctx, WS_BUCKETS, ((size_t)3 * k + 8) * 4, stream));
+            if (!bw) return AT_E_NOMEM;
+            if (fresh || ctx->buckets_k != k) {
+                AT_HIP(hipMemsetAsync(bw, 0, ((size_t)3 * k + 8) * 4, ss));
+                ctx->buckets_k = k;
+            }
+            const size_t lds1 = ((size_t)k + 1) * 4;
+            { const int rcl_ = at_raise_lds(ctx, reinterpret_cast<const void*>(&bucket_count_kernel), lds1); if (rcl_) return rcl_; }
+            int rpb = (int)(n / 1024);
+            rpb = rpb < 512 ? 512 : (rpb > 4096 ? 4096 : rpb);
+            rpb = (rpb + WG - 1) / WG * WG;
+            AT_LAUNCH(bucket_count_kernel, dim3((unsigned)((n + rpb - 1) / rpb)), dim3(WG), lds1, ss, reinterpret_cast<const long*>(ids),
+                      (long)n, k, rpb, bw);
+            AT_LAUNCH(bucket_scan_kernel, dim3(1), dim3(1024), 0, ss, bw, k, 2048u, offsets, bw + (k + 1),
+                      reinterpret_cast<int*>(bw + 2 * (k + 1)));
+            if (!ctx->side_ev2) AT_HIP(hipEventCreateWithFlags(&ctx->side_ev2, hipEventDisableTiming));
+            AT_HIP(hipEventRecord(ctx->side_ev2, ss));
+            offsets_beside = true;
+        }
         AT_LAUNCH(early_count_kernel, dim3(nblk), dim3(WG), 0, ss, reinterpret_cast<const long*>(ids), (long)n, lp.pred, lp.pred_n,
                            nblk, blockcnt);
         AT_LAUNCH(early_scan_kernel, dim3(1), dim3(1024), 0, ss, blockcnt, nblk, blockbase, eoff);
@@ -922,8 +951,11 @@ int at_centroid_accum_f32(at_ctx* ctx, const float* x, int64_t n, int d, const i
         order = vb.current();
         sorted_keys = kb.current();
     }
-    AT_LAUNCH(segment_offsets_kernel, dim3((k + 1 + WG - 1) / WG), dim3(WG), 0, stream,
-                       sorted_keys, (long)n, k, offsets);
+    if (offsets_beside)
+        AT_HIP(hipStreamWaitEvent(stream, ctx->side_ev2, 0));
+    else
+        AT_LAUNCH(segment_offsets_kernel, dim3((k + 1 + WG - 1) / WG), dim3(WG), 0, stream,
+                           sorted_keys, (long)n, k, offsets);
 
     const bool al = at_aligned16(x);
     int vec = 1;

@@ -403,14 +403,18 @@ class Kmeans:
                 ids, dis = be.assign_hinted(xs, cent, ids, order)
             tp = lap("assign", tp)
             part = be.empty((part_len,))
-            be.sum_f64(dis, out=part[obj_off:obj_off + 2].view(torch.float64))   # this rank's objective rides along
+            obj_view = part[obj_off:obj_off + 2].view(torch.float64)             # this rank's objective rides along
+            beside = prune and not member_order and self.order_beside and it + 1 < niter
+            if not beside:
+                be.sum_f64(dis, out=obj_view)
             if prune:
                 # the next iteration's visiting order depends on this assignment only: its sort runs behind
                 # the short-list accumulation while the long lists are still being summed on the side stream
                 if member_order:
                     part, vorder = be.centroid_accum(xs, ids, k, out=part, want_order=True, defer_join=True)
-                elif self.order_beside and it + 1 < niter:
-                    vjoin = be.visit_order_beside(ids, dis, k)   # a third stream: beside both accumulations
+                elif beside:
+                    # a third stream, beside both accumulations: the visiting order of the next iteration and the objective
+                    vjoin = be.visit_order_beside(ids, dis, k, sum_out=obj_view)
                     be.centroid_accum(xs, ids, k, out=part, defer_join=True)
                     vorder = vjoin()
                 else:
