@@ -409,6 +409,22 @@ class HipBackend(HostHelpers):
             return out
         return join
 
+    def sum_beside(self, dis, sum_out):
+        """The objective sum_i dis[i] on the side stream of visit_order_beside; the returned function makes the caller's
+        stream wait for it (iterations that sort nothing beside -- short shards, the last iteration)."""
+        main = torch.cuda.current_stream(self.device)
+        side = getattr(self, "_order_stream", None)
+        if side is None:
+            side = self._order_stream = torch.cuda.Stream(self.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self.sum_f64(dis, out=sum_out)
+            sum_out.record_stream(side)
+
+        def join(dis=dis):
+            torch.cuda.current_stream(self.device).wait_stream(side)
+        return join
+
     def prune_stats(self, reset=False):
         """(accumulators computed, accumulators of the dense sweep) over this context's exact pruned
         sweeps so far.  Synchronises."""

@@ -1299,10 +1299,12 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
                                  aux, nullptr, fuse ? hint_sorted : nullptr, fuse ? dmin : nullptr, fuse ? bd : nullptr,
                                  (fuse || mode != 0) ? dist : nullptr, amb_cap, stream);
         if (rc) return rc;
-        if (dist && fuse) {  // the sweep wrote the guess distances; the rows that moved get theirs here
+        // (asynchronous fused calls: the distance pass rides in the launch that redoes the listed rows, below)
+        const bool finish_fused = dist && fuse && async_form;
+        if (dist && fuse && !finish_fused) {  // the sweep wrote the guess distances; the rows that moved get theirs here
             rc = at_exact_dist_todo(ctx, x, n, D, c, k, ids, dist, stream);
             if (rc) return rc;
-        } else if (dist && mode == 0) {
+        } else if (dist && mode == 0 && !fuse) {
             rc = at_exact_dist_rows(ctx, x, n, D, c, k, ids, dist, order, hint_sorted, bd, stream);
             if (rc) return rc;
         }  // (guess generators wrote an approximate distance themselves: it only orders the next visit)
@@ -1318,8 +1320,12 @@ static int launch_pruned(at_ctx* ctx, const float* x, int64_t n, const float* c,
             int64_t wgs = n / 64;                      // enough workgroups for a list of 1.5 % of the rows in one go
             if (wgs < 256) wgs = 256;
             if (wgs > 65535) wgs = 65535;
-            rc = at_filter_redo_rows(ctx, x, D, c, k, list, wgs, order, cperm, dmin, ng, misc, aux, ids, dist, misc + 64, amb_cap,
-                                     stream);
+            if (finish_fused)
+                rc = at_filter_finish(ctx, x, n, D, c, k, list, wgs, order, cperm, dmin, ng, misc, aux, ids, dist, misc + 64, amb_cap,
+                                      stream);
+            else
+                rc = at_filter_redo_rows(ctx, x, D, c, k, list, wgs, order, cperm, dmin, ng, misc, aux, ids, dist, misc + 64, amb_cap,
+                                         stream);
             if (rc) return rc;
             AT_HIP(hipMemcpyAsync(fs.host_misc, misc, 128 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
             AT_HIP(hipEventRecord(fs.copied, stream));

@@ -254,6 +254,10 @@ int at_filter_gather_ambiguous(at_ctx* ctx, uint32_t* amb_list, uint32_t* amb_so
                                const uint32_t* order, const int64_t* ids, uint32_t* order_amb, uint32_t* hint_amb,
                                hipStream_t stream);
 
+int at_filter_finish(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k, const uint32_t* list, int64_t redo_wgs,
+                     const uint32_t* order, const int32_t* cperm, const float* dmin, int ng, const unsigned* misc,
+                     const uint32_t* aux, int64_t* ids, float* dist, const unsigned* count_dev, unsigned amb_cap,
+                     hipStream_t stream);
 int at_filter_redo_rows(at_ctx* ctx, const float* x, int d, const float* c, int k, const uint32_t* list, int64_t m,
                         const uint32_t* order, const int32_t* cperm, const float* dmin, int ng, const unsigned* misc,
                         const uint32_t* aux, int64_t* ids, float* dist, const unsigned* count_dev, unsigned amb_cap,

@@ -599,8 +599,12 @@ assign_f16filter_kernel(const float* __restrict__ X, long n, const unsigned char
             const unsigned id = slot_id(nj1);
             ids[row_b] = id == NONE ? -1L : (long)id;
             if constexpr (FUSED) {
+                // the guess distance where the winner is the guess; DIST_TODO where the distance pass has to evaluate it;
+                // DIST_LISTED where the redo will (it always writes the distance of a listed row) -- the two passes then
+                // touch disjoint rows and run as one launch (at_filter_finish)
                 if (fp.dist_out)
-                    fp.dist_out[row_b] = (id != NONE && id == hint_b) ? gbd_b : __uint_as_float(DIST_TODO);
+                    fp.dist_out[row_b] = (collect && !unique) ? __uint_as_float(DIST_LISTED)
+                                         : (id != NONE && id == hint_b) ? gbd_b : __uint_as_float(DIST_TODO);
             }
             if constexpr (GUESS) {  // a guess comes with an approximate distance (it only orders the next visit)
                 if (fp.dist_out) fp.dist_out[row_b] = id != NONE ? __builtin_fmaxf(n1 + gbd_b, 0.0f) : __builtin_inff();
@@ -707,11 +711,8 @@ __global__ void __launch_bounds__(WG) exact_dist_visit_kernel(const float* __res
 
 // After a fused sweep: rows whose winner is not their guess still need the contract's distance.
 template <int D>
-__global__ void __launch_bounds__(WG) exact_dist_todo_kernel(const float* __restrict__ X, long n,
-                                                             const float* __restrict__ C, int k,
-                                                             const long* __restrict__ ids,
-                                                             float* __restrict__ dist) {
-    const long i = (long)blockIdx.x * WG + threadIdx.x;
+__device__ __forceinline__ void exact_dist_todo_body(long i, const float* __restrict__ X, long n, const float* __restrict__ C, int k,
+                                                     const long* __restrict__ ids, float* __restrict__ dist) {
     if (i >= n || __float_as_uint(dist[i]) != DIST_TODO) return;
     const long p = ids[i];
     if (p < 0 || p >= k) {
@@ -736,6 +737,13 @@ __global__ void __launch_bounds__(WG) exact_dist_todo_kernel(const float* __rest
         }
     }
     dist[i] = __builtin_fmaxf(__builtin_fmaf(-2.0f, ip, xn + cn), 0.0f);
+}
+template <int D>
+__global__ void __launch_bounds__(WG) exact_dist_todo_kernel(const float* __restrict__ X, long n,
+                                                             const float* __restrict__ C, int k,
+                                                             const long* __restrict__ ids,
+                                                             float* __restrict__ dist) {
+    exact_dist_todo_body<D>((long)blockIdx.x * WG + threadIdx.x, X, n, C, k, ids, dist);
 }
 
 // order_amb[i] = order[pos_i], hint_amb[i] = the filter's winner for that row (a very good guess)
@@ -825,15 +833,13 @@ __global__ void __launch_bounds__(WG) amb_compact_kernel(const unsigned* __restr
 // microseconds per row whatever the neighbours in its tile need -- the MFMA sweep on a sparse list
 // of rows spends its time walking unions of groups instead.
 template <int D>
-__global__ void __launch_bounds__(WG) exact_rows_kernel(const float* __restrict__ X, const float* __restrict__ C, int k,
-                                                        const uint32_t* __restrict__ list,
-                                                        const uint32_t* __restrict__ order,
-                                                        const int32_t* __restrict__ cperm,
-                                                        const float* __restrict__ dmin, int ng,
-                                                        const unsigned* __restrict__ misc,
-                                                        const uint32_t* __restrict__ aux, long* __restrict__ ids,
-                                                        float* __restrict__ dist, const unsigned* __restrict__ count_dev,
-                                                        unsigned amb_cap) {
+__device__ __forceinline__ void exact_rows_body(unsigned vblock, unsigned vgrid, const float* __restrict__ X,
+                                                const float* __restrict__ C, int k, const uint32_t* __restrict__ list,
+                                                const uint32_t* __restrict__ order, const int32_t* __restrict__ cperm,
+                                                const float* __restrict__ dmin, int ng, const unsigned* __restrict__ misc,
+                                                const uint32_t* __restrict__ aux, long* __restrict__ ids, float* __restrict__ dist,
+                                                const unsigned* __restrict__ count_dev, unsigned amb_cap) {
+    // (vblock / vgrid: this workgroup's index among the workgroups that do this job, and how many there are)
     __shared__ int needed[512];
     __shared__ int n_needed;
     __shared__ float red_d[WG / 64];
@@ -844,11 +850,11 @@ __global__ void __launch_bounds__(WG) exact_rows_kernel(const float* __restrict_
     // lengths are read here, on the device, and the grid strides over them (no host round trip; workgroups beyond the
     // list leave at once).  Otherwise: a contiguous list of gridDim.x entries.
     const bool sub = count_dev != nullptr;
-    const unsigned count = sub ? amb_prefix(misc, pre) : gridDim.x;
+    const unsigned count = sub ? amb_prefix(misc, pre) : vgrid;
     // Entries for which the filter left exactly two candidates need two chains, not a workgroup: one
     // thread each, before the workgroup-per-row loop (which then passes over them).
     if (aux) {
-        for (unsigned entry_e = blockIdx.x * WG + tid; entry_e < count; entry_e += gridDim.x * WG) {
+        for (unsigned entry_e = vblock * WG + tid; entry_e < count; entry_e += vgrid * WG) {
             const unsigned entry = sub ? amb_slot(pre, amb_cap, entry_e) : entry_e;
             const uint32_t second = aux[entry];
             if (second >= (uint32_t)k) continue;
@@ -878,7 +884,7 @@ __global__ void __launch_bounds__(WG) exact_rows_kernel(const float* __restrict_
             if (dist) dist[row] = take2 ? d2 : d1;
         }
     }
-    for (unsigned entry_e = blockIdx.x; entry_e < count; entry_e += gridDim.x) {
+    for (unsigned entry_e = vblock; entry_e < count; entry_e += vgrid) {
     const unsigned entry = sub ? amb_slot(pre, amb_cap, entry_e) : entry_e;
     const long row = order[list[entry]];
     const uint32_t second = aux ? aux[entry] : NONE;
@@ -962,6 +968,35 @@ __global__ void __launch_bounds__(WG) exact_rows_kernel(const float* __restrict_
     }
     __syncthreads();  // the shared scratch is reused by the next entry
     }  // entry
+}
+template <int D>
+__global__ void __launch_bounds__(WG) exact_rows_kernel(const float* __restrict__ X, const float* __restrict__ C, int k,
+                                                        const uint32_t* __restrict__ list,
+                                                        const uint32_t* __restrict__ order,
+                                                        const int32_t* __restrict__ cperm,
+                                                        const float* __restrict__ dmin, int ng,
+                                                        const unsigned* __restrict__ misc,
+                                                        const uint32_t* __restrict__ aux, long* __restrict__ ids,
+                                                        float* __restrict__ dist, const unsigned* __restrict__ count_dev,
+                                                        unsigned amb_cap) {
+    exact_rows_body<D>(blockIdx.x, gridDim.x, X, C, k, list, order, cperm, dmin, ng, misc, aux, ids, dist, count_dev, amb_cap);
+}
+// Both jobs behind a fused sweep in ONE launch: the first `todo_blocks` workgroups evaluate the distances the sweep
+// left as DIST_TODO (a linear pass over dist), the others redo the listed rows.  The sweep marks listed rows
+// DIST_LISTED, so the two jobs write disjoint rows.
+template <int D>
+__global__ void __launch_bounds__(WG) exact_finish_kernel(unsigned todo_blocks, long n, const float* __restrict__ X,
+                                                          const float* __restrict__ C, int k, const uint32_t* __restrict__ list,
+                                                          const uint32_t* __restrict__ order, const int32_t* __restrict__ cperm,
+                                                          const float* __restrict__ dmin, int ng, const unsigned* __restrict__ misc,
+                                                          const uint32_t* __restrict__ aux, long* __restrict__ ids,
+                                                          float* __restrict__ dist, const unsigned* __restrict__ count_dev,
+                                                          unsigned amb_cap) {
+    if (blockIdx.x < todo_blocks)
+        exact_dist_todo_body<D>((long)blockIdx.x * WG + threadIdx.x, X, n, C, k, ids, dist);
+    else
+        exact_rows_body<D>(blockIdx.x - todo_blocks, gridDim.x - todo_blocks, X, C, k, list, order, cperm, dmin, ng, misc, aux, ids,
+                           dist, count_dev, amb_cap);
 }
 
 // dmin[p][g] = a lower bound of min over the members m of group g of |c_p - c_m| (prune.hip uses it in
@@ -1260,6 +1295,24 @@ int at_filter_redo_rows(at_ctx* ctx, const float* x, int d, const float* c, int 
     else
         AT_LAUNCH(exact_rows_kernel<128>, dim3((unsigned)m), dim3(WG), 0, stream, x, c, k, list, order, cperm,
                            dmin, ng, misc, aux, reinterpret_cast<long*>(ids), dist, count_dev, amb_cap);
+    return AT_OK;
+}
+
+// The distance pass and the redo of the listed rows behind a fused sweep, one launch (asynchronous exact calls).
+int at_filter_finish(at_ctx* ctx, const float* x, int64_t n, int d, const float* c, int k, const uint32_t* list, int64_t redo_wgs,
+                     const uint32_t* order, const int32_t* cperm, const float* dmin, int ng, const unsigned* misc,
+                     const uint32_t* aux, int64_t* ids, float* dist, const unsigned* count_dev, unsigned amb_cap,
+                     hipStream_t stream) {
+    (void)ctx;
+    AT_REQUIRE(ng <= 512 && dist && redo_wgs > 0, "at_filter_finish: bad arguments");
+    const unsigned todo_blocks = (unsigned)((n + WG - 1) / WG);
+    const dim3 grid(todo_blocks + (unsigned)redo_wgs);
+    if (d == 64)
+        AT_LAUNCH(exact_finish_kernel<64>, grid, dim3(WG), 0, stream, todo_blocks, (long)n, x, c, k, list, order, cperm, dmin, ng,
+                  misc, aux, reinterpret_cast<long*>(ids), dist, count_dev, amb_cap);
+    else
+        AT_LAUNCH(exact_finish_kernel<128>, grid, dim3(WG), 0, stream, todo_blocks, (long)n, x, c, k, list, order, cperm, dmin, ng,
+                  misc, aux, reinterpret_cast<long*>(ids), dist, count_dev, amb_cap);
     return AT_OK;
 }
 

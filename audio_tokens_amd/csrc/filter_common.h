@@ -54,6 +54,7 @@ struct FusedPrepass {
     int ngm;
 };
 constexpr unsigned DIST_TODO = 0x7fc0deadu;  // a NaN no computed distance can be
+constexpr unsigned DIST_LISTED = 0x7fc0beefu; // another one: the row is listed, the redo writes its distance
 constexpr unsigned AMB_SUBLISTS = 64;      // the rows a sweep lists for the redo are appended to 64 sub-lists
 
 }  // namespace atf

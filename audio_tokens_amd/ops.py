@@ -405,8 +405,12 @@ class Kmeans:
             part = be.empty((part_len,))
             obj_view = part[obj_off:obj_off + 2].view(torch.float64)             # this rank's objective rides along
             beside = prune and not member_order and self.order_beside and it + 1 < niter
+            sjoin = None
             if not beside:
-                be.sum_f64(dis, out=obj_view)
+                if prune and hasattr(be, "sum_beside"):
+                    sjoin = be.sum_beside(dis, obj_view)      # beside the accumulation; joined before the partial is used
+                else:
+                    be.sum_f64(dis, out=obj_view)
             if prune:
                 # the next iteration's visiting order depends on this assignment only: its sort runs behind
                 # the short-list accumulation while the long lists are still being summed on the side stream
@@ -421,6 +425,8 @@ class Kmeans:
                     be.centroid_accum(xs, ids, k, out=part, defer_join=True)
                     vorder = be.visit_order(ids, dis, k) if it + 1 < niter else None
                 be.centroid_accum_join()
+                if sjoin is not None:
+                    sjoin()
             else:
                 part, order = be.centroid_accum(xs, ids, k, out=part, want_order=True)
             tp = lap("accumulate", tp)
