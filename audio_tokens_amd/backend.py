@@ -258,6 +258,24 @@ class HipBackend(HostHelpers):
             rec.append(("logmel", n_clips * T, n_mels, hop, e0, e1))
         return out
 
+    def logmel_minmax(self, wave, sample_rate=22050, n_fft=512, hop=128, n_mels=64, fb=None) -> torch.Tensor:
+        """wave [n_clips, L] -> [n_clips, n_mels, T]: logmel() followed by minmax_scale_clips(), one call; the extremes are
+        collected by the log-mel kernel (at_logmel_minmax_f32), so the scaling is a single pass."""
+        wave = self._f32(wave)
+        if wave.dim() == 1:
+            wave = wave.unsqueeze(0)
+        n_clips, L = wave.shape
+        T = self.num_frames(L, hop)
+        fbt = self._f32(fb) if fb is not None else None
+        out = self.empty((n_clips, n_mels, T))
+        with torch.cuda.device(self.device):
+            for c0 in range(0, n_clips, 65535):
+                c1 = min(n_clips, c0 + 65535)
+                _lib.check(self.lib.at_logmel_minmax_f32(
+                    self.ctx.handle, _ptr(wave[c0:c1]), c1 - c0, L, wave.stride(0), sample_rate, n_fft, hop, n_mels,
+                    _ptr(fbt), _ptr(out[c0:c1]), _lib.AT_LAYOUT_MEL_MAJOR, self._stream()))
+        return out
+
     def resample(self, wave, orig_freq: int, new_freq: int) -> torch.Tensor:
         """wave [n_clips, L] (or [L]) -> [n_clips, ceil(L*new/orig)] (torchaudio Resample defaults)."""
         wave = self._f32(wave)

@@ -55,6 +55,7 @@ enum at_ws_slot {
     WS_LOGMEL_ANY,     // log-mel, general n_fft: window, twiddles, banded filterbank
     WS_SUM_TICKET,     // at_sum_f32: arrival counter of its workgroups (the last one adds the partials up), zero between calls
     WS_ROW_FLAG,       // one int: a unit-row pass of at_logmel_f32 met a row whose squared norm is not finite
+    WS_LOGMEL_MINMAX,  // at_logmel_minmax_f32: per clip {min key, max key, NaN flag, pad}
     WS_FILTER_BLKSTATS, // fp16-split filter: one statistics record per workgroup of a sweep (switch filter_stats)
     WS_NSLOTS
 };

@@ -53,7 +53,40 @@ struct LogmelParams {
     float* out;
     int frame_major, fuse_l2norm;
     int* bad;               // set to 1 when a frame's squared norm is not finite (fused unit rows only)
+    unsigned* minmax;       // optional [n_clips][4]: ordered keys of the clip's smallest / largest dB value, a NaN flag
+                            // (at_logmel_minmax_f32: SpectrogramGenerator's normalize option without a reduction pass)
 };
+
+// floats as unsigned keys that order the same way (atomicMin / atomicMax on them)
+__device__ __forceinline__ unsigned ordered_key(float v) {
+    const unsigned b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_to_float(unsigned kx) {
+    return __uint_as_float((kx & 0x80000000u) ? (kx & 0x7fffffffu) : ~kx);
+}
+
+__global__ void __launch_bounds__(256) minmax_init_kernel(unsigned* __restrict__ mm, long n_clips) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c < n_clips) {
+        mm[4 * c] = 0xffffffffu;   // smallest key seen
+        mm[4 * c + 1] = 0u;        // largest
+        mm[4 * c + 2] = 0u;        // a NaN was seen
+        mm[4 * c + 3] = 0u;
+    }
+}
+
+// (spec - min) / (max - min) per clip with the extremes the log-mel kernel collected: two subtractions and one
+// IEEE division per element, torch's bits (processors/spectrogram_generator.py:129-131); a NaN anywhere in the clip
+// makes the whole clip NaN, as torch.min / max propagate it.
+__global__ void __launch_bounds__(256) minmax_apply_kernel(float* __restrict__ x, long clip_elems, const unsigned* __restrict__ mm) {
+    const long clip = blockIdx.y;
+    float lo = key_to_float(mm[4 * clip]), hi = key_to_float(mm[4 * clip + 1]);
+    if (mm[4 * clip + 2]) lo = hi = __builtin_nanf("");
+    const float range = hi - lo;
+    float* p = x + (size_t)clip * clip_elems;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < clip_elems; e += (long)gridDim.x * 256) p[e] = __fdiv_rn(p[e] - lo, range);
+}
 
 // PF: the next block's samples are prefetched through registers (needs a block of at most PREFETCH_REGS x WG x 4
 // samples); otherwise they are staged at the top of the block.
@@ -192,6 +225,29 @@ __global__ void __launch_bounds__(WG, 2) logmel_kernel(LogmelParams p) {
         __syncthreads();
 
         const int nf = min(p.fpb, p.T - t0);  // frames of this block that exist
+        if (p.minmax) {   // the clip's extremes, from the staged block: one pair of atomics per workgroup and block
+            float lo = __builtin_inff(), hi = -__builtin_inff();
+            int nan = 0;
+            for (int e = tid; e < nf * p.n_mels; e += WG) {
+                const int f = e / p.n_mels, m = e - f * p.n_mels;
+                const float v = ostage[f * opitch + m];
+                nan |= v != v;
+                lo = __builtin_fminf(lo, v);
+                hi = __builtin_fmaxf(hi, v);
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                lo = __builtin_fminf(lo, __shfl_xor(lo, off));
+                hi = __builtin_fmaxf(hi, __shfl_xor(hi, off));
+                nan |= __shfl_xor(nan, off);
+            }
+            if (lane == 0) {
+                if (lo <= hi) {
+                    atomicMin(&p.minmax[4 * clip], ordered_key(lo));
+                    atomicMax(&p.minmax[4 * clip + 1], ordered_key(hi));
+                }
+                if (nan) atomicOr(&p.minmax[4 * clip + 2], 1u);
+            }
+        }
         if (p.frame_major) {
             float* den = ostage + p.fpb * opitch;
             if (p.fuse_l2norm) {
@@ -349,11 +405,10 @@ int build_tables(at_ctx* ctx, int sample_rate, int n_mels, int hop, const float*
 
 }  // namespace
 
-extern "C" int at_logmel_f32(at_ctx* ctx, const float* wave, int64_t n_clips, int64_t L,
-                             int64_t wave_stride, int sample_rate, int n_fft, int hop, int n_mels,
-                             const float* fb_or_null, float* out, int layout, int fuse_l2norm,
-                             void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+static int logmel_impl(at_ctx* ctx, const float* wave, int64_t n_clips, int64_t L,
+                       int64_t wave_stride, int sample_rate, int n_fft, int hop, int n_mels,
+                       const float* fb_or_null, float* out, int layout, int fuse_l2norm,
+                       unsigned* minmax, hipStream_t stream) {
     AT_REQUIRE(ctx, "at_logmel_f32: ctx is null");
     AT_REQUIRE(n_fft >= 64 && n_fft <= 4096 && (n_fft & (n_fft - 1)) == 0,
                "at_logmel_f32: n_fft=%d not supported (a power of two from 64 to 4096)", n_fft);
@@ -394,6 +449,7 @@ extern "C" int at_logmel_f32(at_ctx* ctx, const float* wave, int64_t n_clips, in
     p.out = out; p.frame_major = layout == AT_LAYOUT_FRAME_MAJOR; p.fuse_l2norm = fuse_here;
     p.bad = fuse_l2norm ? at_row_flag(ctx, stream) : nullptr;
     if (fuse_l2norm && !p.bad) return AT_E_NOMEM;
+    p.minmax = minmax;
     // the banded filterbank rides in LDS too unless a dense user filterbank makes it too big
     const size_t fb_ints = (((size_t)3 * n_mels + 3) & ~(size_t)3) + p.fb_nw;
     p.fb_lds = fb_ints * 4 <= 14 * 1024;
@@ -417,5 +473,46 @@ extern "C" int at_logmel_f32(at_ctx* ctx, const float* wave, int64_t n_clips, in
     if (pf) AT_LAUNCH(logmel_kernel<true>, dim3((unsigned)grid), dim3(WG), lds, stream, p);
     else AT_LAUNCH(logmel_kernel<false>, dim3((unsigned)grid), dim3(WG), lds, stream, p);
     if (fuse_l2norm && !fuse_here) return at_l2norm_rows_flagged(ctx, out, n_clips * T, n_mels, out, p.bad, stream);
+    return AT_OK;
+}
+
+extern "C" int at_logmel_f32(at_ctx* ctx, const float* wave, int64_t n_clips, int64_t L,
+                             int64_t wave_stride, int sample_rate, int n_fft, int hop, int n_mels,
+                             const float* fb_or_null, float* out, int layout, int fuse_l2norm,
+                             void* stream_) {
+    return logmel_impl(ctx, wave, n_clips, L, wave_stride, sample_rate, n_fft, hop, n_mels, fb_or_null, out, layout,
+                       fuse_l2norm, nullptr, (hipStream_t)stream_);
+}
+
+// MelSpectrogram + AmplitudeToDB + normalize_spectrogram (processors/spectrogram_generator.py:123-131 with
+// config.normalize = True): the log-mel kernel collects every clip's smallest and largest dB value while the block it
+// has just computed is still in LDS, so the scaling is ONE pass over the spectrogram (8 B per value) instead of a
+// reduction pass plus a scaling pass (12 B).  Other n_fft than 512: the general log-mel kernel, then the two-pass form.
+extern "C" int at_logmel_minmax_f32(at_ctx* ctx, const float* wave, int64_t n_clips, int64_t L, int64_t wave_stride,
+                                    int sample_rate, int n_fft, int hop, int n_mels, const float* fb_or_null, float* out,
+                                    int layout, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AT_REQUIRE(ctx, "at_logmel_minmax_f32: ctx is null");
+    if (n_clips == 0) return AT_OK;
+    AT_REQUIRE(hop >= 1, "at_logmel_minmax_f32: hop=%d out of range", hop);
+    const int64_t clip_elems = at_num_frames(L, hop) * n_mels;
+    if (n_fft != NFFT) {
+        int rc = logmel_impl(ctx, wave, n_clips, L, wave_stride, sample_rate, n_fft, hop, n_mels, fb_or_null, out, layout, 0,
+                             nullptr, stream);
+        if (rc) return rc;
+        return at_minmax_scale_clips_f32(ctx, out, n_clips, clip_elems, stream_);
+    }
+    AT_REQUIRE(n_clips <= 65535, "at_logmel_minmax_f32: at most 65535 clips per call");
+    AT_HIP(hipSetDevice(ctx->device));
+    unsigned* mm = static_cast<unsigned*>(at_ws(ctx, WS_LOGMEL_MINMAX, (size_t)n_clips * 16, stream));
+    if (!mm) return AT_E_NOMEM;
+    AT_LAUNCH(minmax_init_kernel, dim3((unsigned)((n_clips + 255) / 256)), dim3(256), 0, stream, mm, (long)n_clips);
+    int rc = logmel_impl(ctx, wave, n_clips, L, wave_stride, sample_rate, n_fft, hop, n_mels, fb_or_null, out, layout, 0, mm,
+                         stream);
+    if (rc) return rc;
+    int bx = (int)((clip_elems + 256 * 8 - 1) / (256 * 8));
+    if (bx < 1) bx = 1;
+    if (bx > 64) bx = 64;
+    AT_LAUNCH(minmax_apply_kernel, dim3((unsigned)bx, (unsigned)n_clips), dim3(256), 0, stream, out, (long)clip_elems, mm);
     return AT_OK;
 }

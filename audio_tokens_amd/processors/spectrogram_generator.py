@@ -125,9 +125,13 @@ class SpectrogramGenerator:
                 self.logger.debug(f"clips shorter than the reflect padding skipped: {len(js)}")
                 continue
             batch = torch.stack([waves[j].reshape(-1).to(self.device) for j in js])
-            out = self.spec_transformer(batch)                       # [B, n_mels, T] on the GPU
-            if self.config.normalize:   # one launch for the batch (the reference: three torch reductions per clip)
-                out = self.spec_transformer.backend.minmax_scale_clips(out.contiguous())
+            if self.config.normalize:
+                # the batch's log-mel with the per-clip (spec - min) / (max - min) behind it in one call: the extremes come
+                # out of the log-mel kernel itself (the reference: three torch reductions and two passes per clip)
+                st = self.spec_transformer
+                out = st.backend.logmel_minmax(batch, st.sample_rate, st.n_fft, st.hop_length, st.n_mels, fb=st.fb)
+            else:
+                out = self.spec_transformer(batch)                   # [B, n_mels, T] on the GPU
             finite = torch.isfinite(out).flatten(1).all(dim=1).cpu()
             out = out.cpu()  # one bulk device->host copy; the per-file .cpu() in run() is then free
             for b, j in enumerate(js):

@@ -116,6 +116,15 @@ int at_l2norm_rows_f32(at_ctx* ctx, const float* x, int64_t n, int d, float* y, 
  * fp32 operations (same bits as the reference's torch expression). */
 int at_minmax_scale_clips_f32(at_ctx* ctx, float* x, int64_t n_clips, int64_t clip_elems, void* stream);
 
+/* generate_mel_spectrogram followed by normalize_spectrogram (processors/spectrogram_generator.py:123-131 with
+ * config.normalize = True) for a batch of clips: at_logmel_f32(..., fuse_l2norm = 0) and at_minmax_scale_clips_f32
+ * in one call, same bits.  The log-mel kernel collects every clip's extremes while a computed block is still in LDS,
+ * so the scaling costs one pass over the spectrogram instead of a reduction pass plus a scaling pass.  At most
+ * 65535 clips per call. */
+int at_logmel_minmax_f32(at_ctx* ctx, const float* wave, int64_t n_clips, int64_t L, int64_t wave_stride,
+                         int sample_rate, int n_fft, int hop, int n_mels, const float* fb_or_null,
+                         float* out, int layout, void* stream);
+
 /* Nearest centroid under squared L2 (IndexFlatL2.search(x, 1)):
  *   dis(i,j) = max(0, (|x_i|^2 + |c_j|^2) - 2 <x_i, c_j>), all fp32, inner products and norms as
  *   ascending-index fmaf chains (v_mfma_f32_32x32x2_f32); ids[i] = lowest j attaining the minimum.

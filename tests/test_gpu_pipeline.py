@@ -291,6 +291,17 @@ def test_normalize_option_is_one_kernel_with_torchs_bits(workdir, be):
     assert torch.equal(got[:9].view(torch.int32), want[:9].view(torch.int32))
     assert torch.equal(got[10:].view(torch.int32), want[10:].view(torch.int32))
     assert bool(torch.isnan(got[9]).all()) and bool(torch.isnan(want[9]).all())
+    # the fused form (extremes collected inside the log-mel kernel, one scaling pass): a NaN sample makes its clip NaN
+    from audio_tokens_amd.synth import synth_clips
+    for n_fft, hop in ((512, 128), (1024, 512)):
+        wave = synth_clips(9, L=30000, seed=5, device=be.device)
+        wave[4, 12345] = float("nan")
+        spec = be.logmel(wave, 22050, n_fft, hop, 64)
+        want = torch.stack([SpectrogramGenerator.normalize_spectrogram(s) for s in spec])
+        got = be.logmel_minmax(wave, 22050, n_fft, hop, 64)
+        ok = [i for i in range(9) if i != 4]
+        assert torch.equal(got[ok].view(torch.int32), want[ok].view(torch.int32)), (n_fft, hop)
+        assert bool(torch.isnan(got[4]).all()) and bool(torch.isnan(want[4]).all())
     plain = SpectrogramGenerator(cfg).populate_specs(split["train"][:5])
     normed = SpectrogramGenerator(dataclasses.replace(cfg, normalize=True)).populate_specs(split["train"][:5])
     for a, b in zip(plain, normed):
