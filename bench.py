@@ -352,7 +352,7 @@ def main():
                                    {"launches": D["launches"], "avg_ms": D["ms"] / max(1, D["launches"]),
                                     "share_of_step_time": step_share(D["ms"])}),
                     "note": "frac = issued fp16 MFMA flop / dense fp16 MFMA peak (the kernel is latency-bound: see DESIGN.md section 5); "
-                            "hbm_frac = PMC bytes per launch / launch time / 8 TB/s on the Lloyd-sweep form of the kernel"}
+                            "hbm_frac = PMC bytes per launch / launch time under the profiler / 8 TB/s, measured on the form of the kernel that is timed here (a Lloyd-shaped sweep over a random subsample: profiles/kernel_traffic.json)"}
     else:
         flop = sum(2.0 * n * d * k for (_, n, d, k, _, _) in D["sel"])
         achieved = flop / (D["ms"] * 1e-3) / 1e12 if D["ms"] > 0 else 0.0
