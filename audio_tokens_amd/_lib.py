@@ -47,6 +47,7 @@ SIGNATURES = {
     "at_resample_taps_host": (_i32, [_i32, _i32, _c.POINTER(_i32), _c.POINTER(_i32), _c.POINTER(_i32), _vp, _i64]),
     "at_resample_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),
     "at_minmax_scale_clips_f32": (_i32, [_vp, _vp, _i64, _i64, _vp]),
+    "at_conv1d_mel_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "at_logmel_minmax_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "at_l2norm_rows_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "at_assign_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp]),

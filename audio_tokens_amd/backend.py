@@ -323,6 +323,20 @@ class HipBackend(HostHelpers):
                                                               specs[0].numel(), self._stream()))
         return specs
 
+    def conv1d_mel(self, frames, weight, bias=None, padding=1) -> torch.Tensor:
+        """frames [n, n_mels] -> [n, n_mels * num_kernels]: nn.Conv1d(1, num_kernels, kernel_size, padding) along the mel
+        axis, feature = mel * num_kernels + kernel (at_conv1d_mel_f32).  weight: the module's [num_kernels, 1, kernel_size]."""
+        frames = self._f32(frames)
+        n, n_mels = frames.shape
+        w = self._f32(weight).reshape(weight.shape[0], -1).contiguous()
+        b = self._f32(bias).contiguous() if bias is not None else None
+        nk, ks = w.shape
+        out = self.empty((n, n_mels * nk))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.at_conv1d_mel_f32(self.ctx.handle, _ptr(frames), n, n_mels, _ptr(w), _ptr(b), nk, ks, int(padding),
+                                                  _ptr(out), self._stream()))
+        return out
+
     def l2norm_rows(self, x, out=None) -> torch.Tensor:
         x = self._f32(x)
         assert x.dim() == 2

@@ -82,6 +82,55 @@ __global__ void __launch_bounds__(1024) minmax_scale_kernel(float* __restrict__ 
 
 }  // namespace
 
+namespace {
+// ClusterCreator / SpecTokenizer.apply_convolution (processors/cluster_creator.py:68-81, spec_tokenizer.py:92-104,115-121):
+// nn.Conv1d(1, num_kernels, kernel_size, padding) along the mel axis of every frame, output laid out as the reference's
+// transpose(1, 2).reshape does: feature = mel * num_kernels + kernel.  One thread per output value; a frame's n_mels
+// inputs are read through L1 by the num_kernels * kernel_size threads that need them, the outputs (num_kernels x the
+// input bytes: the pass is bound by its stores) leave coalesced.  Arithmetic: bias, then the taps in ascending order,
+// one fmaf each.
+__global__ void __launch_bounds__(256) conv1d_mel_kernel(const float* __restrict__ x, long n, int n_mels,
+                                                         const float* __restrict__ w, const float* __restrict__ bias, int nk,
+                                                         int ks, int pad, float* __restrict__ out) {
+    extern __shared__ float wsh[];   // nk * ks weights, nk biases
+    for (int i = threadIdx.x; i < nk * ks + nk; i += 256) wsh[i] = i < nk * ks ? w[i] : (bias ? bias[i - nk * ks] : 0.0f);
+    __syncthreads();
+    const long d_out = (long)n_mels * nk;
+    const long total = n * d_out;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long row = e / d_out;
+        const int f = (int)(e - row * d_out);
+        const int m = f / nk, j = f - m * nk;
+        const float* xr = x + row * n_mels;
+        float acc = wsh[nk * ks + j];
+        for (int t = 0; t < ks; t++) {
+            const int mm = m + t - pad;
+            const float v = (mm >= 0 && mm < n_mels) ? xr[mm] : 0.0f;
+            acc = __builtin_fmaf(wsh[j * ks + t], v, acc);
+        }
+        out[e] = acc;
+    }
+}
+}  // namespace
+
+extern "C" int at_conv1d_mel_f32(at_ctx* ctx, const float* x, int64_t n, int n_mels, const float* weight, const float* bias_or_null,
+                                 int num_kernels, int kernel_size, int padding, float* out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AT_REQUIRE(ctx && n >= 0 && n_mels > 0 && num_kernels > 0 && kernel_size > 0 && padding >= 0, "at_conv1d_mel_f32: bad arguments");
+    AT_REQUIRE(2 * padding == kernel_size - 1, "at_conv1d_mel_f32: only 'same' convolutions (2 * padding == kernel_size - 1), as the reference's");
+    AT_REQUIRE((num_kernels * kernel_size + num_kernels) * sizeof(float) <= 32 * 1024, "at_conv1d_mel_f32: too many weights");
+    if (n == 0) return AT_OK;
+    AT_REQUIRE(x && weight && out, "at_conv1d_mel_f32: null pointer");
+    AT_HIP(hipSetDevice(ctx->device));
+    const long total = n * (long)n_mels * num_kernels;
+    long blocks = (total + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 8L * ctx->n_cus) blocks = 8L * ctx->n_cus;
+    if (blocks < 1) blocks = 1;
+    AT_LAUNCH(conv1d_mel_kernel, dim3((unsigned)blocks), dim3(256), (size_t)(num_kernels * kernel_size + num_kernels) * sizeof(float), stream, x,
+              (long)n, n_mels, weight, bias_or_null, num_kernels, kernel_size, padding, out);
+    return AT_OK;
+}
+
 extern "C" int at_minmax_scale_clips_f32(at_ctx* ctx, float* x, int64_t n_clips, int64_t clip_elems, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     AT_REQUIRE(ctx && n_clips >= 0 && n_clips <= 0x7fffffffL && clip_elems > 0, "at_minmax_scale_clips_f32: bad arguments");

@@ -78,15 +78,16 @@ class ClusterCreator:
         """vectors / (||vectors||_2 + 1e-10) row-wise; same bits as the reference's numpy lines."""
         return normalize_rows(vectors)
 
-    def _convolve_device(self, frames, chunk=1 << 20):
-        """frames [n, n_mels] (device) -> [n, num_kernels * n_mels] (device), feature = mel * num_kernels + kernel."""
-        out = torch.empty((frames.shape[0], self.config.num_kernels * self.config.n_mels), dtype=torch.float32,
-                          device=frames.device)
+    def _convolve_device(self, frames):
+        """frames [n, n_mels] (device) -> [n, num_kernels * n_mels] (device): the module's Conv1d along the mel axis, feature
+        index = mel * num_kernels + kernel, as the reference's transpose(1, 2).reshape lays it out -- one HIP kernel
+        (at_conv1d_mel_f32) with the module's weights; the module itself only provides them (torch's RNG, as in the
+        reference)."""
+        from ..backend import default_backend
+        be = default_backend()
         with torch.no_grad():
-            for r0 in range(0, frames.shape[0], chunk):
-                y = self.conv(frames[r0:r0 + chunk].unsqueeze(1))
-                out[r0:r0 + chunk] = y.transpose(1, 2).reshape(y.shape[0], -1)
-        return out
+            return be.conv1d_mel(frames, self.conv.weight.detach(), self.conv.bias.detach() if self.conv.bias is not None else None,
+                                 padding=int(self.conv.padding[0]))
 
     def apply_convolution(self, time_slice_batch):
         frames = torch.as_tensor(np.asarray(time_slice_batch), device=self.device).float()

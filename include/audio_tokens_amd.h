@@ -116,6 +116,15 @@ int at_l2norm_rows_f32(at_ctx* ctx, const float* x, int64_t n, int d, float* y, 
  * fp32 operations (same bits as the reference's torch expression). */
 int at_minmax_scale_clips_f32(at_ctx* ctx, float* x, int64_t n_clips, int64_t clip_elems, void* stream);
 
+/* ClusterCreator.apply_convolution / SpecTokenizer.apply_convolution (processors/cluster_creator.py:68-81,
+ * processors/spec_tokenizer.py:92-104,115-121; config.use_convolution): nn.Conv1d(1, num_kernels, kernel_size,
+ * padding = (kernel_size - 1) / 2) along the mel axis of every frame.  x: [n][n_mels]; weight: DEVICE
+ * [num_kernels][kernel_size] (the module's weight[:, 0, :]); bias_or_null: DEVICE [num_kernels];
+ * out: [n][n_mels * num_kernels] with feature = mel * num_kernels + kernel (the reference's transpose + reshape).
+ * out(m, j) = fma chain over the taps in ascending order, started from the bias. */
+int at_conv1d_mel_f32(at_ctx* ctx, const float* x, int64_t n, int n_mels, const float* weight, const float* bias_or_null,
+                      int num_kernels, int kernel_size, int padding, float* out, void* stream);
+
 /* generate_mel_spectrogram followed by normalize_spectrogram (processors/spectrogram_generator.py:123-131 with
  * config.normalize = True) for a batch of clips: at_logmel_f32(..., fuse_l2norm = 0) and at_minmax_scale_clips_f32
  * in one call, same bits.  The log-mel kernel collects every clip's extremes while a computed block is still in LDS,

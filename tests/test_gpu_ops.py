@@ -374,6 +374,28 @@ def test_centroid_accum_sort_path_with_more_long_clusters_than_early_slots(be, s
         assert np.array_equal(bits(p[: k * d].reshape(k, d)), bits(sums)), call
 
 
+@pytest.mark.parametrize("n_mels,nk,ks", [(64, 10, 3), (128, 10, 3), (40, 4, 5), (64, 1, 1)])
+def test_conv1d_mel_matches_torch(be, n_mels, nk, ks):
+    """use_convolution (SURVEY 8f row 3): Conv1d(1, nk, ks, padding=ks//2) along the mel axis by at_conv1d_mel_f32 against
+    torch's conv1d on the CPU (tolerance: the two sum the taps in their own order) and, exactly, against the taps added
+    in ascending order in float64 rounded once per fma; layout feature = mel * nk + kernel."""
+    torch.manual_seed(n_mels + nk)
+    conv = torch.nn.Conv1d(1, nk, ks, padding=ks // 2)
+    x = torch.randn(5000, n_mels) * 20 - 30
+    with torch.no_grad():
+        want = conv(x.unsqueeze(1)).transpose(1, 2).reshape(x.shape[0], -1)
+    got = be.conv1d_mel(x, conv.weight.detach(), conv.bias.detach(), padding=ks // 2).cpu()
+    assert got.shape == want.shape
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-5)
+    # the kernel's own definition: bias, then fmaf per tap in ascending order (an fma = exact product, one rounding)
+    w = conv.weight.detach().reshape(nk, ks).double().numpy(); b = conv.bias.detach().double().numpy()
+    xp = np.pad(x.numpy().astype(np.float64), ((0, 0), (ks // 2, ks // 2)))
+    acc = np.broadcast_to(b.astype(np.float32)[None, None, :], (x.shape[0], n_mels, nk)).copy()
+    for t in range(ks):
+        acc = (acc.astype(np.float64) + xp[:, t:t + n_mels, None] * w[None, None, :, t]).astype(np.float32)
+    assert np.array_equal(bits(got.numpy().reshape(x.shape[0], n_mels, nk)), bits(acc))
+
+
 def test_sum_and_nonfinite(be):
     rng = np.random.default_rng(1)
     v = rng.random(1_000_003).astype(np.float32)
