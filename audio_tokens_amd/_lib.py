@@ -32,6 +32,7 @@ SIGNATURES = {
     "at_create": (_i32, [_i32, _c.POINTER(_vp)]),
     "at_destroy": (None, [_vp]),
     "at_workspace_bytes": (_i64, [_vp]),
+    "at_background_stream": (_i32, [_vp, _c.POINTER(_vp)]),
     "at_debug_set": (_i32, [_vp, _c.c_char_p, _i32]),
     "at_debug_get": (_i32, [_vp, _c.c_char_p, _c.POINTER(_i32)]),
     "at_diag_errors": (_i32, [_c.POINTER(_i64), _c.POINTER(_i32), _c.POINTER(_i64), _c.POINTER(_i32), _c.c_char_p, _i32, _i32]),

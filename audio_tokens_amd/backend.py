@@ -214,6 +214,15 @@ class HipBackend(HostHelpers):
     def synchronize(self) -> None:
         torch.cuda.current_stream(self.device).synchronize()
 
+    def background_stream(self):
+        """The context's lowest-priority stream as a torch stream (at_background_stream): `with torch.cuda.stream(s)`
+        routes this backend's launches there."""
+        if getattr(self, "_bg_stream", None) is None:
+            h = ctypes.c_void_p()
+            _lib.check(self.lib.at_background_stream(self.ctx.handle, ctypes.byref(h)))
+            self._bg_stream = torch.cuda.ExternalStream(h.value, device=self.device)
+        return self._bg_stream
+
     def record_event_timed(self):
         """record_event with timing: `a.elapsed_time(b)` between two of them once both have completed."""
         ev = torch.cuda.Event(enable_timing=True)

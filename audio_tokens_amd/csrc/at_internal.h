@@ -11,6 +11,23 @@
 #include "../../include/audio_tokens_amd.h"
 #include "../../include/at_debug.h"
 
+// Kernels that a caller may put on a stream of its own beside the k-means / tokenise sweeps (the pipeline computes the
+// log-mel frames of later batches on the context's background stream) are compiled WITHOUT packed-fp32 vector
+// instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 / v_pk_mov_b32).  Measured on gfx950 (ROCm 7.2.0, round 3,
+// profiles/r03_packed_fp32_beside_mfma.txt): while a wave of another kernel keeps the same SIMD's matrix pipe busy with
+// back-to-back v_mfma_f32_32x32x16_f16 (the fp16 filter in guess mode: three products per tile), the packed ops of the
+// 512-point log-mel kernel returned wrong values in lanes 48..63 of single registers -- 1.3e4 wrong frames of 1.0e7,
+// always the frame owned by the wave's last 16 lanes, with either register allocation (223 / 190 VGPRs), with or without
+// an s_waitcnt behind every LDS access, at 32 or 16 frames per block; the same source compiled with
+// target("no-packed-fp32-ops") gave 0 wrong frames under the same load, at the same speed (2.62 ms per 3.4 M frames).
+// The sweeps' own packed ops have never differed from the dense reference (bench.py `verified`, tests/test_gpu_*), so the
+// rule is applied to the producers only.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AT_NO_PACKED_FP32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define AT_NO_PACKED_FP32
+#endif
+
 // Workspace slots of a context (grown on demand, never shrunk).
 enum at_ws_slot {
     WS_CENT_IMG = 0,   // assign: tiled/swizzled centroid image + |c|^2
@@ -122,6 +139,7 @@ struct at_ctx {
     int filter_force_sync;
   // 32x32 tiles multiplied (hi*hi) / refined (lo products too), exact calls
     hipStream_t side_stream;             // centroid_accum: long member lists beside the short ones
+    hipStream_t background_stream;       // at_background_stream: lowest priority, lent to the caller
     hipEvent_t side_ev[2];
     hipEvent_t side_ev2;                 // behind the segment offsets computed beside the sort (centroid_accum, radix path)
     int defer_join, join_pending;        // at_centroid_accum_defer / at_centroid_accum_join

@@ -179,6 +179,7 @@ void at_destroy(at_ctx* ctx) {
     }
     if (ctx->side_ev2) (void)AT_HIP_TOLERATE(hipEventDestroy(ctx->side_ev2));
     if (ctx->side_stream) (void)AT_HIP_TOLERATE(hipStreamDestroy(ctx->side_stream));
+    if (ctx->background_stream) (void)AT_HIP_TOLERATE(hipStreamDestroy(ctx->background_stream));
     if (ctx->mt_ready) (void)AT_HIP_TOLERATE(hipEventDestroy(ctx->mt_ready));
     if (ctx->sum_ev) (void)AT_HIP_TOLERATE(hipEventDestroy(ctx->sum_ev));
     if (ctx->filter_host_misc) (void)AT_HIP_TOLERATE(hipHostFree(ctx->filter_host_misc));
@@ -186,6 +187,18 @@ void at_destroy(at_ctx* ctx) {
     std::free(ctx->any_user_copy);
     (void)AT_HIP_TOLERATE(hipSetDevice(prev));
     delete ctx;
+}
+
+int at_background_stream(at_ctx* ctx, void** stream_out) {
+    AT_REQUIRE(ctx && stream_out, "at_background_stream: null pointer");
+    if (!ctx->background_stream) {
+        AT_HIP(hipSetDevice(ctx->device));
+        int least = 0, greatest = 0;   // numerically: least >= greatest (lower numbers are served first)
+        AT_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        AT_HIP(hipStreamCreateWithPriority(&ctx->background_stream, hipStreamNonBlocking, least));
+    }
+    *stream_out = ctx->background_stream;
+    return AT_OK;
 }
 
 int64_t at_workspace_bytes(const at_ctx* ctx) {

@@ -54,6 +54,8 @@ class DevicePipeline:
         self.be = backend or default_backend()
         self.verbose = verbose
         self.prune = prune   # False: plain dense sweeps everywhere (bench.py's floor / verification run)
+        self.overlap_logmel = os.environ.get("AT_OVERLAP_LOGMEL", "1") != "0"
+        self.beside_clips = int(os.environ.get("AT_BESIDE_CLIPS", "50"))   # clips per side-stream log-mel launch
         self.world = 1
         if distributed:
             import torch.distributed as dist
@@ -73,21 +75,81 @@ class DevicePipeline:
                       frame_major=True, l2norm=True, out=out[c0 * T:c1 * T])
         return out, T
 
+    def _frames_beside(self, wave_tr, wave_va, per_rank):
+        """Log-mel of everything but the first k-means batch on a side stream, in launches of a few hundred clips, so
+        that it runs in the gaps of the Lloyd iterations of the batches before it (the tail of an iteration -- member
+        lists, centroid sums, regrouping -- is a chain of small launches that leaves most of the chip idle, and the
+        log-mel kernel is bound by latency, not by a unit the sweep saturates).  Returns the frame tensors, T, one event
+        per k-means batch (its frames are complete), the event behind the validation frames, and faiss' input-check flag
+        of the TRAINING frames (taken on the side stream between the two sets)."""
+        be = self.be
+        n_clips, L = wave_tr.shape
+        T = be.num_frames(L, self.hop_length)
+        main = torch.cuda.current_stream(be.device)
+        if getattr(self, "_lm_stream", None) is None:
+            # the lowest priority there is: the Lloyd iterations' own launches go first whenever both are ready
+            # (torch's own stream pool offers "normal" and "high" only)
+            self._lm_stream = be.background_stream() if os.environ.get("AT_BESIDE_PRIO", "1") != "0" else torch.cuda.Stream(device=be.device)
+        side = self._lm_stream
+        frames_tr = be.empty((n_clips * T, self.n_mels))
+        n_va = 0 if wave_va is None else wave_va.shape[0]
+        frames_va = be.empty((n_va * T, self.n_mels)) if n_va else None
+        take_flag = hasattr(be, "logmel_nonfinite_take")
+        if take_flag:
+            be.logmel_nonfinite_take()                 # (whatever earlier log-mel passes of this context left behind)
+
+        def logmel(wave, frames, c0, c1):
+            be.logmel(wave[c0:c1], self.sample_rate, self.n_fft, self.hop_length, self.n_mels, frame_major=True, l2norm=True,
+                      out=frames[c0 * T:c1 * T])
+
+        first = min(n_clips, per_rank)
+        for c0 in range(0, first, self.spectrogram_batch_size):
+            logmel(wave_tr, frames_tr, c0, min(first, c0 + self.spectrogram_batch_size))
+        ready = [torch.cuda.Event()]
+        ready[0].record(main)
+        piece = self.beside_clips
+        bad = None
+        with torch.cuda.stream(side):
+            side.wait_event(ready[0])                  # (also orders the side stream behind the allocation of the frames)
+            for b0 in range(first, n_clips, per_rank):
+                b1 = min(n_clips, b0 + per_rank)
+                for c0 in range(b0, b1, piece):
+                    logmel(wave_tr, frames_tr, c0, min(b1, c0 + piece))
+                ev = torch.cuda.Event()
+                ev.record(side)
+                ready.append(ev)
+            if take_flag:
+                bad = be.logmel_nonfinite_take()
+            for c0 in range(0, n_va, piece):
+                logmel(wave_va, frames_va, c0, min(n_va, c0 + piece))
+            done = torch.cuda.Event()
+            done.record(side)
+        return frames_tr, frames_va, T, ready, done, bad
+
     def run(self, wave_train, wave_val=None, timing=False) -> PipelineResult:
         be = self.be
         sync = be.synchronize if timing else (lambda: None)
         secs = {}
+        per_rank = max(1, self.clustering_batch_size // self.world)
 
         t0 = time.perf_counter()
         take_flag = hasattr(be, "logmel_nonfinite_take")
-        if take_flag:
-            be.logmel_nonfinite_take()                 # (whatever earlier log-mel passes of this context left behind)
-        frames_tr, T = self._frames(be._f32(wave_train))
-        # faiss' input check (Clustering::train) on the training frames, from the unit-row pass that wrote them
-        bad = be.logmel_nonfinite_take() if take_flag else None
-        frames_va = None
-        if wave_val is not None and wave_val.shape[0] > 0:
-            frames_va, _ = self._frames(be._f32(wave_val))
+        # timing=True keeps the stages apart (stage_seconds are stand-alone costs); otherwise the log-mel of later
+        # k-means batches and of the validation clips runs beside the training of the batches before them
+        beside = self.overlap_logmel and not timing and be.device.type == "cuda" and wave_train.shape[0] > per_rank
+        ready = done = None
+        if beside:
+            frames_tr, frames_va, T, ready, done, bad = self._frames_beside(
+                be._f32(wave_train), be._f32(wave_val) if wave_val is not None and wave_val.shape[0] > 0 else None, per_rank)
+        else:
+            if take_flag:
+                be.logmel_nonfinite_take()                 # (whatever earlier log-mel passes of this context left behind)
+            frames_tr, T = self._frames(be._f32(wave_train))
+            # faiss' input check (Clustering::train) on the training frames, from the unit-row pass that wrote them
+            bad = be.logmel_nonfinite_take() if take_flag else None
+            frames_va = None
+            if wave_val is not None and wave_val.shape[0] > 0:
+                frames_va, _ = self._frames(be._f32(wave_val))
         sync(); secs["logmel"] = time.perf_counter() - t0
 
         # k-means: one train() per batch of `clustering_batch_size` files (this rank's share of
@@ -97,13 +159,16 @@ class DevicePipeline:
                     distributed=self.distributed, process_group=self.process_group, backend=be)
         km.prune = self.prune
         n_clips = wave_train.shape[0]
-        per_rank = max(1, self.clustering_batch_size // self.world)
         pending = []
         if bad is None:
+            if done is not None:
+                torch.cuda.current_stream(be.device).wait_event(done)
             bad = be.nonfinite_flag(frames_tr)     # faiss' input check (Clustering::train), once for all batches
         for b, c0 in enumerate(range(0, n_clips, per_rank)):
             c1 = min(n_clips, c0 + per_rank)
             x = frames_tr[c0 * T:c1 * T]
+            if ready is not None:
+                torch.cuda.current_stream(be.device).wait_event(ready[b])
             # (no host round trip inside: the frames were scanned for NaN/Inf once, above; the statistics of
             # every batch are read back after the last one)
             km.train(x, init_centroids=None if b == 0 else km.centroids_device, sync=False, check_finite=False)
@@ -116,6 +181,8 @@ class DevicePipeline:
         index = IndexFlatL2(self.n_mels, backend=be)          # SpecTokenizer.load_centroid_index
         index.prune = self.prune
         index.add(centroids)
+        if done is not None:
+            torch.cuda.current_stream(be.device).wait_event(done)
         tok_tr, _ = index.assign(frames_tr, want_dist=False)  # index.search(x, 1), ids only
         tok_va = be.empty((0,), torch.int64)
         if frames_va is not None:

@@ -390,6 +390,11 @@ def main():
             "frames_per_step": frames_per_step, "parallelism": f"dp{world}",
         },
         "stage_seconds": stage,
+        "stage_seconds_note": ("stand-alone cost of each stage, from one extra step with a synchronisation between the stages"
+                               + (f"; in the timed steps the log-mel of every k-means batch after the first and of the validation "
+                                  f"clips runs on a background stream beside the training of the batches before it "
+                                  f"({pipe.beside_clips} clips per launch), so the stages sum to more than ms_per_step"
+                                  if pipe.overlap_logmel else "")),
         "stage_seconds_per_rank": stage_all,
         "warmup_step_ms": warm_ms,
         "traced_step_ms": traced_ms,

@@ -67,6 +67,11 @@ int at_create(int device, at_ctx** out);
 void at_destroy(at_ctx* ctx);
 /* bytes of device workspace currently held by the context */
 int64_t at_workspace_bytes(const at_ctx* ctx);
+/* A stream of the LOWEST priority the device offers, owned by the context (created on first use, destroyed by
+ * at_destroy): for work that should fill the gaps of the caller's main stream without delaying it -- the pipeline
+ * computes the log-mel frames of the k-means batches to come there while the batch before them is trained
+ * (cluster_creator.py:42-56 loads batch by batch too).  *stream_out is a hipStream_t. */
+int at_background_stream(at_ctx* ctx, void** stream_out);
 
 /* ---- host helpers (no GPU work) --------------------------------------------------------------*/
 /* faiss utils/random.cpp rand_perm(perm, n, seed): std::mt19937 Fisher-Yates. perm: host [n]. */

@@ -351,3 +351,69 @@ def test_device_pipeline_rejects_nonfinite_input_without_a_scan(be):
         assert int(be.logmel_nonfinite_take().item()) == 0
         be.logmel(wave[:3], n_mels=n_mels, frame_major=True, l2norm=True)
         assert int(be.logmel_nonfinite_take().item()) == 0
+
+
+def test_logmel_beside_the_training_changes_nothing(be):
+    """DevicePipeline.run computes the frames of the later k-means batches and of the validation clips on the context's
+    background stream while the batches before them are trained: same centroids and tokens as the sequential form, the
+    input check still sees a NaN in ANY training batch, and validation clips stay outside it (the reference's validation
+    spectrograms never reach faiss.Kmeans.train: cluster_creator.py:42-56 reads the train split only)."""
+    from audio_tokens_amd.pipeline import DevicePipeline
+    from audio_tokens_amd.synth import synth_clips
+    wave = synth_clips(23, L=22050 * 2, seed=11, device="cuda")
+    pipe = DevicePipeline(n_mels=64, vocab_size=128, niter=4, clustering_batch_size=6, backend=be)
+    pipe.beside_clips = 2
+    assert pipe.overlap_logmel
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = pipe.run(wave[:20], wave[20:])
+        pipe.overlap_logmel = False
+        b = pipe.run(wave[:20], wave[20:])
+        pipe.overlap_logmel = True
+        assert torch.equal(a.centroids.view(torch.int32), b.centroids.view(torch.int32))
+        assert torch.equal(a.tokens_train, b.tokens_train) and torch.equal(a.tokens_val, b.tokens_val)
+        dirty = wave.clone()
+        dirty[15, 9000] = float("nan")                # third k-means batch: computed on the side stream
+        with pytest.raises(RuntimeError, match="isfinite"):
+            pipe.run(dirty[:20], dirty[20:])
+        dirty = wave.clone()
+        dirty[21, 9000] = float("nan")                # a validation clip
+        c = pipe.run(dirty[:20], dirty[20:])
+        assert torch.equal(a.centroids.view(torch.int32), c.centroids.view(torch.int32)) and torch.equal(a.tokens_train, c.tokens_train)
+        assert torch.equal(pipe.run(wave[:20], wave[20:]).tokens_val, a.tokens_val)
+
+
+
+def test_logmel_is_unchanged_beside_guess_mode_sweeps(be):
+    """Round 3's finding (csrc/at_internal.h AT_NO_PACKED_FP32, profiles/r03_packed_fp32_beside_mfma.txt): with
+    packed-fp32 instructions the 512-point log-mel kernel returned wrong frames while the fp16 filter ran in guess mode
+    on another stream (dense f16 MFMAs on the same SIMDs).  The producers are compiled without them; this is the load
+    under which ~1 frame in 800 used to come out wrong."""
+    from audio_tokens_amd.synth import synth_clips
+    wave = synth_clips(1500, L=220500, seed=5, device="cuda")
+    rng = np.random.default_rng(5)
+    k, n = 8192, 1 << 20
+    c = rng.standard_normal((k, 64)).astype(np.float32)
+    c /= np.linalg.norm(c, axis=1, keepdims=True)
+    C = be._f32(c)
+    xs = torch.nn.functional.normalize(torch.randn(n, 64, device="cuda"), dim=1)
+    cperm = be.from_host(be.group_rows_kd(c))
+    means = be.group_means(C, cperm)
+    quiet = [be.logmel(wave[c0:c0 + 50], frame_major=True, l2norm=True).clone() for c0 in range(0, 1500, 50)]
+    torch.cuda.synchronize()
+    main, bg = torch.cuda.current_stream(), be.background_stream()
+    for rep in range(2):
+        ev = torch.cuda.Event(); ev.record(main)
+        with torch.cuda.stream(bg):
+            bg.wait_event(ev)
+            got = [be.logmel(wave[c0:c0 + 50], frame_major=True, l2norm=True) for c0 in range(0, 1500, 50)]
+            done = torch.cuda.Event(); done.record(bg)
+        overlapped = 0
+        for _ in range(12):
+            be._nearest_mean(xs, means)             # the fp16 filter in guess mode over the group means
+            overlapped += not done.query()
+        main.wait_event(done)
+        torch.cuda.synchronize()
+        assert overlapped >= 3, "the sweeps did not run beside the log-mel launches: the test tested nothing"
+        for a, b in zip(quiet, got):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
