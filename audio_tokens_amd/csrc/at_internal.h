@@ -13,20 +13,17 @@
 
 // Kernels that a caller may put on a stream of its own beside the k-means / tokenise sweeps (the pipeline computes the
 // log-mel frames of later batches on the context's background stream) are compiled WITHOUT packed-fp32 vector
-// instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 / v_pk_mov_b32).  Measured on gfx950 (ROCm 7.2.0, round 3,
-// profiles/r03_packed_fp32_beside_mfma.txt): while a wave of another kernel keeps the same SIMD's matrix pipe busy with
-// back-to-back v_mfma_f32_32x32x16_f16 (the fp16 filter in guess mode: three products per tile), the packed ops of the
-// 512-point log-mel kernel returned wrong values in lanes 48..63 of single registers -- 1.3e4 wrong frames of 1.0e7,
-// always the frame owned by the wave's last 16 lanes, with either register allocation (223 / 190 VGPRs), with or without
-// an s_waitcnt behind every LDS access, at 32 or 16 frames per block; the same source compiled with
-// target("no-packed-fp32-ops") gave 0 wrong frames under the same load, at the same speed (2.62 ms per 3.4 M frames).
-// The sweeps' own packed ops have never differed from the dense reference (bench.py `verified`, tests/test_gpu_*), so the
-// rule is applied to the producers only.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define AT_NO_PACKED_FP32 __attribute__((target("no-packed-fp32-ops")))
-#else
-#define AT_NO_PACKED_FP32
-#endif
+// instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 / v_pk_mov_b32): Makefile, NOPK_OBJS.  Measured on gfx950
+// (ROCm 7.2.0, round 3, profiles/r03_packed_fp32_beside_mfma.txt): while a wave of another kernel keeps the same SIMD's
+// matrix pipe busy with back-to-back v_mfma_f32_32x32x16_f16 (the fp16 filter in guess mode: three products per tile), the
+// packed ops of the 512-point log-mel kernel returned wrong values in lanes 48..63 of single registers -- 1.3e4 wrong
+// frames of 1.0e7, always the frame owned by the wave's last 16 lanes, with either register allocation (223 / 190 VGPRs),
+// with or without an s_waitcnt behind every LDS access, at 32 or 16 frames per block; the same source compiled without
+// packed ops gave 0 wrong frames under the same load, at the same speed.  The sweeps' own packed ops have never differed
+// from the dense reference (bench.py `verified`, tests/test_gpu_*) and produce the same guesses with and without, so the
+// rule is applied to the producers only.  (A target("no-packed-fp32-ops") attribute on the kernels does the same but keeps
+// the always-inline helpers from being inlined into them -- 30 calls and a scratch frame in the log-mel kernel --, and
+// -Xarch_device -mno-packed-fp32-ops is accepted and ignored.)
 
 // Workspace slots of a context (grown on demand, never shrunk).
 enum at_ws_slot {

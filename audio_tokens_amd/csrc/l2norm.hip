@@ -19,7 +19,7 @@ namespace {
 constexpr int WG = 256;
 
 // bad (optional): set to 1 when a row's norm is not finite, i.e. when the row holds a NaN or Inf (or its squares overflow)
-__global__ void __launch_bounds__(WG) AT_NO_PACKED_FP32 l2norm_rows_kernel(const float* __restrict__ x, long n, int d,
+__global__ void __launch_bounds__(WG) l2norm_rows_kernel(const float* __restrict__ x, long n, int d,
                                                          int rows_per_block, float* __restrict__ y, int* __restrict__ bad) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // R*(d+1) floats + R floats
     const int R = rows_per_block;
@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(WG) AT_NO_PACKED_FP32 l2norm_rows_kernel(const
 // processors/spectrogram_generator.py:129-131): (spec - min) / (max - min) with torch's fp32 operations -- two
 // subtractions and one IEEE division per element.  One workgroup per clip: the reduction pass pulls the clip
 // (441 KB at 64 x 1723) through L2, the scaling pass reads it from there.  NaN propagates as in torch.min / max.
-__global__ void __launch_bounds__(1024) AT_NO_PACKED_FP32 minmax_scale_kernel(float* __restrict__ x, long clip_elems) {
+__global__ void __launch_bounds__(1024) minmax_scale_kernel(float* __restrict__ x, long clip_elems) {
     __shared__ float s_lo[16], s_hi[16];
     __shared__ int s_nan[16];
     float* p = x + (size_t)blockIdx.x * clip_elems;
@@ -89,7 +89,7 @@ namespace {
 // inputs are read through L1 by the num_kernels * kernel_size threads that need them, the outputs (num_kernels x the
 // input bytes: the pass is bound by its stores) leave coalesced.  Arithmetic: bias, then the taps in ascending order,
 // one fmaf each.
-__global__ void __launch_bounds__(256) AT_NO_PACKED_FP32 conv1d_mel_kernel(const float* __restrict__ x, long n, int n_mels,
+__global__ void __launch_bounds__(256) conv1d_mel_kernel(const float* __restrict__ x, long n, int n_mels,
                                                          const float* __restrict__ w, const float* __restrict__ bias, int nk,
                                                          int ks, int pad, float* __restrict__ out) {
     extern __shared__ float wsh[];   // nk * ks weights, nk biases

@@ -7,17 +7,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-// (no packed-fp32 instructions in code that may run beside the sweeps: at_internal.h, AT_NO_PACKED_FP32)
-#if defined(__HIP_DEVICE_COMPILE__)
-#define L2N_DEV __device__ inline __attribute__((target("no-packed-fp32-ops")))
-#else
-#define L2N_DEV __device__ inline
-#endif
-
 namespace l2n {
 
 // a[0], a[stride], ... a[(n-1)*stride]
-L2N_DEV float pairwise_sumsq(const float* a, int n, int stride) {
+__device__ inline float pairwise_sumsq(const float* a, int n, int stride) {
 #pragma clang fp contract(off)
     if (n < 8) {
         float res = 0.0f;
@@ -54,7 +47,7 @@ L2N_DEV float pairwise_sumsq(const float* a, int n, int stride) {
 // The same value for 8 <= n <= 128 computed by 8 adjacent lanes (j = lane & 7 owns numpy's partial sum
 // r[j]; the combining tree is numpy's, and fp32 addition is commutative, so every lane ends with numpy's
 // bits).  All 8 lanes must call it together.
-L2N_DEV float pairwise_sumsq_8lanes(const float* a, int n, int j) {
+__device__ inline float pairwise_sumsq_8lanes(const float* a, int n, int j) {
 #pragma clang fp contract(off)
     float r = a[j] * a[j];
     int i;
@@ -73,11 +66,11 @@ L2N_DEV float pairwise_sumsq_8lanes(const float* a, int n, int j) {
 }
 
 // ||row|| + 1e-10 as numpy computes it for a float32 row
-L2N_DEV float row_denominator(const float* a, int n, int stride) {
+__device__ inline float row_denominator(const float* a, int n, int stride) {
     return __builtin_sqrtf(pairwise_sumsq(a, n, stride)) + 1e-10f;
 }
 
 // x / den, IEEE-rounded
-L2N_DEV float divide(float x, float den) { return x / den; }
+__device__ inline float divide(float x, float den) { return x / den; }
 
 }  // namespace l2n

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) minmax_init_kernel(unsigned* __restrict__
 // (spec - min) / (max - min) per clip with the extremes the log-mel kernel collected: two subtractions and one
 // IEEE division per element, torch's bits (processors/spectrogram_generator.py:129-131); a NaN anywhere in the clip
 // makes the whole clip NaN, as torch.min / max propagate it.
-__global__ void __launch_bounds__(256) AT_NO_PACKED_FP32 minmax_apply_kernel(float* __restrict__ x, long clip_elems, const unsigned* __restrict__ mm) {
+__global__ void __launch_bounds__(256) minmax_apply_kernel(float* __restrict__ x, long clip_elems, const unsigned* __restrict__ mm) {
     const long clip = blockIdx.y;
     float lo = key_to_float(mm[4 * clip]), hi = key_to_float(mm[4 * clip + 1]);
     if (mm[4 * clip + 2]) lo = hi = __builtin_nanf("");
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256) AT_NO_PACKED_FP32 minmax_apply_kernel(flo
 // PF: the next block's samples are prefetched through registers (needs a block of at most PREFETCH_REGS x WG x 4
 // samples); otherwise they are staged at the top of the block.
 template <bool PF>
-__global__ void __launch_bounds__(WG, 2) AT_NO_PACKED_FP32 logmel_kernel(LogmelParams p) {
+__global__ void __launch_bounds__(WG, 2) logmel_kernel(LogmelParams p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, grp = lane >> 4;

@@ -38,7 +38,7 @@ struct AnyParams {
 
 __device__ __forceinline__ unsigned bitrev(unsigned v, int bits) { return __brev(v) >> (32 - bits); }
 
-__global__ void __launch_bounds__(WG) AT_NO_PACKED_FP32 logmel_any_kernel(AnyParams p) {
+__global__ void __launch_bounds__(WG) logmel_any_kernel(AnyParams p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // per wave: n_fft floats (z) + M + 4 floats (power)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int N = p.n_fft, M = N >> 1;

@@ -17,7 +17,7 @@ namespace {
 
 constexpr int WG = 256;
 
-__global__ void __launch_bounds__(WG) AT_NO_PACKED_FP32 resample_kernel(const float* __restrict__ wave, long n_clips, long L,
+__global__ void __launch_bounds__(WG) resample_kernel(const float* __restrict__ wave, long n_clips, long L,
                                                       long wave_stride, const float* __restrict__ taps, int orig,
                                                       int nw, int K, int width, long out_len, long out_stride,
                                                       float* __restrict__ out) {
@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(WG) AT_NO_PACKED_FP32 resample_kernel(const fl
 // interleaved so that consecutive lanes read consecutive steps.  The accumulation order is the
 // same ascending-k fma chain as resample_kernel, so both produce identical bits.
 template <int RI>
-__global__ void __launch_bounds__(WG) AT_NO_PACKED_FP32 resample_tiled_kernel(const float* __restrict__ wave, long L, long wave_stride,
+__global__ void __launch_bounds__(WG) resample_tiled_kernel(const float* __restrict__ wave, long L, long wave_stride,
                                                             const float* __restrict__ taps, int orig, int nw, int K,
                                                             int width, int TI, int interleave, long out_len,
                                                             long out_stride, float* __restrict__ out) {
