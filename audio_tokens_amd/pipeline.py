@@ -126,6 +126,15 @@ class DevicePipeline:
             done.record(side)
         return frames_tr, frames_va, T, ready, done, bad
 
+    def overlaps_logmel(self, n_train_clips) -> bool:
+        """Whether run() computes the later batches' frames beside the training: only where a training is long enough
+        to hide them -- the pruned path of large vocabularies (a Lloyd iteration of ~1.4 ms with a tail of small
+        launches); at vocab_size 500 a whole training is 6 ms and the 50-clip launches cost more than they hide
+        (configs[1]: 59 -> 64 ms per step when tried)."""
+        per_rank = max(1, self.clustering_batch_size // self.world)
+        return (self.overlap_logmel and self.be.device.type == "cuda" and n_train_clips > per_rank and self.prune
+                and self.vocab_size >= 1024 and self.n_mels in (64, 128))
+
     def run(self, wave_train, wave_val=None, timing=False) -> PipelineResult:
         be = self.be
         sync = be.synchronize if timing else (lambda: None)
@@ -136,7 +145,7 @@ class DevicePipeline:
         take_flag = hasattr(be, "logmel_nonfinite_take")
         # timing=True keeps the stages apart (stage_seconds are stand-alone costs); otherwise the log-mel of later
         # k-means batches and of the validation clips runs beside the training of the batches before them
-        beside = self.overlap_logmel and not timing and be.device.type == "cuda" and wave_train.shape[0] > per_rank
+        beside = not timing and self.overlaps_logmel(wave_train.shape[0])
         ready = done = None
         if beside:
             frames_tr, frames_va, T, ready, done, bad = self._frames_beside(

@@ -360,27 +360,27 @@ def test_logmel_beside_the_training_changes_nothing(be):
     spectrograms never reach faiss.Kmeans.train: cluster_creator.py:42-56 reads the train split only)."""
     from audio_tokens_amd.pipeline import DevicePipeline
     from audio_tokens_amd.synth import synth_clips
-    wave = synth_clips(23, L=22050 * 2, seed=11, device="cuda")
-    pipe = DevicePipeline(n_mels=64, vocab_size=128, niter=4, clustering_batch_size=6, backend=be)
+    wave = synth_clips(27, L=22050 * 2, seed=11, device="cuda")
+    pipe = DevicePipeline(n_mels=64, vocab_size=1024, niter=4, clustering_batch_size=6, backend=be)
     pipe.beside_clips = 2
-    assert pipe.overlap_logmel
+    assert pipe.overlaps_logmel(24)               # (the form is taken for large vocabularies only: DevicePipeline.overlaps_logmel)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        a = pipe.run(wave[:20], wave[20:])
+        a = pipe.run(wave[:24], wave[24:])
         pipe.overlap_logmel = False
-        b = pipe.run(wave[:20], wave[20:])
+        b = pipe.run(wave[:24], wave[24:])
         pipe.overlap_logmel = True
         assert torch.equal(a.centroids.view(torch.int32), b.centroids.view(torch.int32))
         assert torch.equal(a.tokens_train, b.tokens_train) and torch.equal(a.tokens_val, b.tokens_val)
         dirty = wave.clone()
         dirty[15, 9000] = float("nan")                # third k-means batch: computed on the side stream
         with pytest.raises(RuntimeError, match="isfinite"):
-            pipe.run(dirty[:20], dirty[20:])
+            pipe.run(dirty[:24], dirty[24:])
         dirty = wave.clone()
-        dirty[21, 9000] = float("nan")                # a validation clip
-        c = pipe.run(dirty[:20], dirty[20:])
+        dirty[25, 9000] = float("nan")                # a validation clip
+        c = pipe.run(dirty[:24], dirty[24:])
         assert torch.equal(a.centroids.view(torch.int32), c.centroids.view(torch.int32)) and torch.equal(a.tokens_train, c.tokens_train)
-        assert torch.equal(pipe.run(wave[:20], wave[20:]).tokens_val, a.tokens_val)
+        assert torch.equal(pipe.run(wave[:24], wave[24:]).tokens_val, a.tokens_val)
 
 
 
@@ -402,18 +402,21 @@ def test_logmel_is_unchanged_beside_guess_mode_sweeps(be):
     quiet = [be.logmel(wave[c0:c0 + 50], frame_major=True, l2norm=True).clone() for c0 in range(0, 1500, 50)]
     torch.cuda.synchronize()
     main, bg = torch.cuda.current_stream(), be.background_stream()
+    be._nearest_mean(xs, means)                     # (its cached helpers exist before the timed part)
+    torch.cuda.synchronize()
     for rep in range(2):
-        ev = torch.cuda.Event(); ev.record(main)
-        with torch.cuda.stream(bg):
-            bg.wait_event(ev)
-            got = [be.logmel(wave[c0:c0 + 50], frame_major=True, l2norm=True) for c0 in range(0, 1500, 50)]
-            done = torch.cuda.Event(); done.record(bg)
-        overlapped = 0
-        for _ in range(12):
+        ev0 = torch.cuda.Event(enable_timing=True); ev0.record(main)
+        for _ in range(60):
             be._nearest_mean(xs, means)             # the fp16 filter in guess mode over the group means
-            overlapped += not done.query()
-        main.wait_event(done)
+        main_end = torch.cuda.Event(enable_timing=True); main_end.record(main)
+        with torch.cuda.stream(bg):
+            bg.wait_event(ev0)
+            got = [be.logmel(wave[c0:c0 + 50], frame_major=True, l2norm=True) for c0 in range(0, 1500, 50)]
+            bg_end = torch.cuda.Event(enable_timing=True); bg_end.record(bg)
+        main.wait_event(bg_end)
         torch.cuda.synchronize()
-        assert overlapped >= 3, "the sweeps did not run beside the log-mel launches: the test tested nothing"
+        # both chains start at ev0: the log-mel launches ran beside the sweeps if they were through before the sweeps were
+        assert ev0.elapsed_time(bg_end) < ev0.elapsed_time(main_end), \
+            f"the sweeps did not run beside the log-mel launches ({ev0.elapsed_time(bg_end):.2f} ms against {ev0.elapsed_time(main_end):.2f} ms)"
         for a, b in zip(quiet, got):
             assert torch.equal(a.view(torch.int32), b.view(torch.int32))
