@@ -474,11 +474,12 @@ def test_logmel_other_hops_and_widths(be, oracle, hop, n_mels):
 
 
 @pytest.mark.parametrize("n_fft,hop,n_mels", [(1024, 512, 64), (1024, 256, 128), (256, 64, 40), (2048, 512, 64), (64, 16, 8),
-                                              (4096, 1024, 128)])
+                                              (4096, 1024, 128), (128, 32, 20)])   # (every pass sequence: 8,4 / 8,8 / 8,8,2 / 8,8,8 / 8,8,8,2 / 8,8,8,4)
 def test_logmel_other_nfft(be, oracle, n_fft, hop, n_mels):
     """n_fft is a configuration knob of the reference (audio_tokens_config.py:39; its README documents 1024 / 512):
-    every power of two other than the tuned 512 goes through the general radix-2 kernel -- same tolerance against
-    the oracle, both layouts, unit rows, a user filterbank, silence exactly -100 dB."""
+    every power of two other than the tuned 512 goes through the general kernel (Stockham radix-8 passes, one template
+    instance per size) -- same tolerance against the oracle, both layouts, unit rows, a user filterbank, silence exactly
+    -100 dB."""
     rng = np.random.default_rng(n_fft + hop)
     L = 30001
     clips = (0.1 * rng.standard_normal((4, L))).astype(np.float32)
