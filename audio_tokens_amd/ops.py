@@ -593,6 +593,13 @@ class IndexFlatL2:
                 self._prune = (cperm, be.group_min_dist(c, cperm), be.group_neighbours(be.group_means(c, cperm), 4))
             cperm, dmin, gnbr = self._prune
             return be.assign_c2f(x, c, cperm, dmin, gnbr, want_dist=want_dist, coherent=self.rows_coherent)
+        if (self.prune and hasattr(be, "assign_unguided") and self.d in (64, 128) and 128 <= k < 1024 and x.shape[0] >= 65536
+                and getattr(be, "switches", {}).get("filter", True)):
+            # too few centroids to prune (configs[1]: k = 500), enough rows to pay for the set-up: the same fp16-split
+            # filter, every group visited
+            if self._prune is None:
+                self._prune = (be.from_host(be.group_rows_kd(be.to_host(c))), None, None)
+            return be.assign_unguided(x, c, want_dist=want_dist, cperm=self._prune[0])
         return be.assign(x, c, want_dist=want_dist)
 
     def search(self, x, k=1):

@@ -31,6 +31,31 @@ def test_assign_bit_exact(be, oracle, n, d, k):
     assert np.array_equal(bits(dis), bits(dis_o))
 
 
+@pytest.mark.parametrize("n,d,k", [(70000, 64, 500), (66000, 128, 300), (100000, 64, 1000), (65536, 64, 128)])
+def test_assign_unguided_small_tables_bit_exact(be, oracle, n, d, k):
+    """Tables too small to prune (configs[1]: vocab_size 500) go through the fp16-split filter with every group
+    visited (HipBackend.assign_unguided; IndexFlatL2.assign takes it for 128 <= k < 1024 and >= 65536 rows): same ids
+    and distances as the oracle's brute force, exact ties and duplicated centroids included."""
+    from audio_tokens_amd.ops import IndexFlatL2
+    rng = np.random.default_rng(n + k)
+    centers = _unit_rows(rng, k, d, oracle)
+    x = oracle.l2norm_rows((centers[rng.integers(0, k, n)] + 0.3 * rng.standard_normal((n, d))).astype(np.float32))
+    c = centers.copy()
+    c[k // 2: k // 2 + 10] = c[0:10]                  # duplicates: the lowest index wins
+    x[:10] = c[k // 2: k // 2 + 10]
+    x[10:20] *= 7.5                                   # un-normalised rows
+    ids_o, dis_o = oracle.assign(x, c)
+    ids, dis = be.assign_unguided(x, c)
+    assert np.array_equal(ids.cpu().numpy(), ids_o)
+    assert np.array_equal(bits(dis.cpu().numpy()), bits(dis_o))
+    index = IndexFlatL2(d, backend=be)
+    index.add(c)
+    be.filter_stats()
+    D, I = index.search(x, 1)
+    assert be.filter_stats()[0] == n                  # (the search went through the filter sweep)
+    assert np.array_equal(I[:, 0], ids_o) and np.array_equal(bits(D[:, 0]), bits(dis_o))
+
+
 def test_assign_unnormalised_and_ties(be, oracle):
     rng = np.random.default_rng(5)
     # un-normalised rows, duplicated centroids (exact ties -> lowest index), duplicated rows
