@@ -73,7 +73,7 @@ def cpu_logmel_torch(wave, n_mels, hop, n_fft=512, sr=22050):
     return torch.cat(out).reshape(-1, n_mels).numpy()               # frame-major, as the k-means stage wants it
 
 
-def cpu_baseline(n_mels, vocab, L, hop, seed, clips, niter):
+def cpu_baseline(n_mels, vocab, L, hop, seed, clips, niter, gpu_note=""):
     """The CPU path timed on this box's host cores on a bounded sample of the same workload (kind="port": faiss and
     torchaudio are not installable here).  Log-mel: torch.stft-based, fp32, torch's CPU threads (SURVEY.md section 8d);
     the oracle's double-precision log-mel is timed beside it.  K-means and tokenise: the oracle (C, OpenMP).
@@ -105,8 +105,8 @@ def cpu_baseline(n_mels, vocab, L, hop, seed, clips, niter):
         "kind": "port",
         "sample": (f"{clips} clips ({frames} frames) of the same synthetic stream: torch.stft log-mel (fp32, {torch.get_num_threads()} "
                    f"torch threads), then the oracle with {oracle.num_threads()} OpenMP threads: one Kmeans.train (k={vocab}, niter={niter} "
-                   f"-- the GPU step runs 60 Lloyd sweeps over 2.1 M rows per 43 M frames, i.e. 2.9 sweeps per frame, so 3 "
-                   f"iterations over the sample's frames do the same work per frame) and tokenise; "
+                   f"-- {gpu_note}, so {niter} iteration{'s' if niter != 1 else ''} over the sample's frames "
+                   f"{'do the same work per frame' if niter > 1 else 'are the least a training can do'}) and tokenise; "
                    f"seconds: logmel {t1 - t0:.2f}, kmeans {t2 - t1:.2f}, tokenise {t3 - t2:.2f}; the oracle's own "
                    f"double-precision log-mel takes {(t4 - t3) * clips / max(1, clips // 4):.2f} s for the same clips; "
                    f"host has {os.cpu_count()} logical cores"),
@@ -441,7 +441,14 @@ def main():
         del hres
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(n_mels, vocab, L, hop, seed, args.cpu_clips, niter=3)
+        # Lloyd sweeps the GPU step makes per frame it processes: trainings x niter x subsample rows / frames (2.9 on the
+        # configs[3] shard, 0.2 at configs[1]); the CPU sample trains with that many iterations over ITS frames, at least one
+        n_trains = -(-n_tr // 10000)
+        sub_rows = min(256 * vocab, min(n_tr, 10000) * T)
+        per_frame = n_trains * args.niter * sub_rows / ((n_tr + n_va) * T)
+        out["cpu_baseline"] = cpu_baseline(n_mels, vocab, L, hop, seed, args.cpu_clips, niter=max(1, round(per_frame)),
+                                           gpu_note=f"the GPU step runs {n_trains * args.niter} Lloyd sweeps over {sub_rows} rows per "
+                                                    f"{(n_tr + n_va) * T} frames, i.e. {per_frame:.1f} sweeps per frame")
     else:
         out["cpu_baseline"] = None
     if rank == 0:
