@@ -105,8 +105,8 @@ def cpu_baseline(n_mels, vocab, L, hop, seed, clips, niter, gpu_note=""):
         "kind": "port",
         "sample": (f"{clips} clips ({frames} frames) of the same synthetic stream: torch.stft log-mel (fp32, {torch.get_num_threads()} "
                    f"torch threads), then the oracle with {oracle.num_threads()} OpenMP threads: one Kmeans.train (k={vocab}, niter={niter} "
-                   f"-- {gpu_note}, so {niter} iteration{'s' if niter != 1 else ''} over the sample's frames "
-                   f"{'do the same work per frame' if niter > 1 else 'are the least a training can do'}) and tokenise; "
+                   f"-- {gpu_note}: {niter} iteration{'s' if niter != 1 else ''} over the sample's frames "
+                   f"{'do the same work per frame' if niter > 1 else 'is the least a training can do'}) and tokenise; "
                    f"seconds: logmel {t1 - t0:.2f}, kmeans {t2 - t1:.2f}, tokenise {t3 - t2:.2f}; the oracle's own "
                    f"double-precision log-mel takes {(t4 - t3) * clips / max(1, clips // 4):.2f} s for the same clips; "
                    f"host has {os.cpu_count()} logical cores"),
