@@ -30,7 +30,7 @@ with warnings.catch_warnings():
     ref = pipe.run(wt, wv)
     diff(ref, pipe.run(wt, wv), "sequential again")
     pipe.overlap_logmel = True
-    for i in range(4):
+    for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
         diff(ref, pipe.run(wt, wv), f"beside #{i}")
     d = mk(False)
     diff(ref, d.run(wt, wv), "dense beside")
