@@ -421,6 +421,28 @@ def test_conv1d_mel_matches_torch(be, n_mels, nk, ks):
     assert np.array_equal(bits(got.numpy().reshape(x.shape[0], n_mels, nk)), bits(acc))
 
 
+def test_new_entry_points_edges(be):
+    """Edges of round 3's entry points: no bias / empty input / a convolution that is not 'same' (at_conv1d_mel_f32);
+    the background stream is one stream per context, usable as a torch stream; an empty batch of clips for the fused
+    min-max form."""
+    from audio_tokens_amd import _lib
+    x = torch.randn(100, 64, device="cuda")
+    w = torch.randn(4, 1, 3)
+    y = be.conv1d_mel(x, w, None, padding=1).cpu()
+    want = torch.nn.functional.conv1d(x.cpu().unsqueeze(1), w, None, padding=1).transpose(1, 2).reshape(100, -1)
+    assert torch.allclose(y, want, rtol=1e-5, atol=1e-5)
+    assert be.conv1d_mel(x[:0], w, None, padding=1).shape == (0, 256)
+    with pytest.raises(_lib.NativeError, match="only 'same' convolutions"):
+        be.conv1d_mel(x, w, None, padding=0)
+    s1, s2 = be.background_stream(), be.background_stream()
+    assert s1.cuda_stream == s2.cuda_stream and s1.cuda_stream != torch.cuda.current_stream().cuda_stream
+    with torch.cuda.stream(s1):
+        z = be.l2norm_rows(x)
+    s1.synchronize()
+    assert torch.equal(z, be.l2norm_rows(x))
+    assert tuple(be.logmel_minmax(torch.zeros(0, 22050, device="cuda")).shape) == (0, 64, 173)
+
+
 def test_sum_and_nonfinite(be):
     rng = np.random.default_rng(1)
     v = rng.random(1_000_003).astype(np.float32)
