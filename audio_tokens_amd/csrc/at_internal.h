@@ -19,7 +19,10 @@
 // packed ops of the 512-point log-mel kernel returned wrong values in lanes 48..63 of single registers -- 1.3e4 wrong
 // frames of 1.0e7, always the frame owned by the wave's last 16 lanes, with either register allocation (223 / 190 VGPRs),
 // with or without an s_waitcnt behind every LDS access, at 32 or 16 frames per block; the same source compiled without
-// packed ops gave 0 wrong frames under the same load, at the same speed.  The sweeps' own packed ops have never differed
+// packed ops gave 0 wrong frames under the same load, at the same speed.  The form that fails (tools/pk_probe.py: one
+// packed instruction per victim kernel, checked in place against the unpacked one) is v_pk_add_f32 with an op_sel half-swizzle
+// of a vector-register source -- what the compiler emits for complex arithmetic; plain, negated, scalar- and constant-operand
+// forms showed 0 mismatches in 1e11 operations each.  The sweeps' own packed ops have never differed
 // from the dense reference (bench.py `verified`, tests/test_gpu_*) and produce the same guesses with and without, so the
 // rule is applied to the producers only.  (A target("no-packed-fp32-ops") attribute on the kernels does the same but keeps
 // the always-inline helpers from being inlined into them -- 30 calls and a scratch frame in the log-mel kernel --, and
